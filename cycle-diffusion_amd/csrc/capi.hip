@@ -1,0 +1,571 @@
+// extern "C" boundary (include/cyclediff.h): engine lifetime, weight loading, the sampler loops
+// (DPM-Encoder / coupled decode) and single-kernel entry points used by the parity tests.
+#include <string.h>
+
+#include <algorithm>
+
+#include "engine.h"
+
+using namespace cd;
+
+struct cd_engine {
+  hipStream_t st = nullptr;
+  Arena arena;
+  bf16_t* zeros = nullptr;
+  float* gn_partial = nullptr;
+  size_t gn_partial_floats = 0;
+  std::vector<std::unique_ptr<Net>> nets;
+  std::vector<ParamStore*> op_stores;  // storage behind cd_op_pack_conv
+  ParamStore op_params;
+  Ctx ctx() {
+    Ctx c; c.st = st; c.arena = &arena; c.zeros = zeros; c.gn_partial = gn_partial;
+    c.gn_partial_floats = gn_partial_floats;
+    return c;
+  }
+};
+
+static thread_local std::string g_err;
+
+#define CD_API_BEGIN try {
+#define CD_API_END                                  \
+  }                                                 \
+  catch (const std::exception& e) {                 \
+    g_err = e.what();                               \
+    return 1;                                       \
+  }                                                 \
+  catch (...) {                                     \
+    g_err = "unknown C++ exception";                \
+    return 1;                                       \
+  }                                                 \
+  return 0;
+
+static UNet* get_unet(cd_handle h, int net) {
+  CD_CHECK(h && net >= 0 && net < (int)h->nets.size(), "bad net id %d", net);
+  Net* n = h->nets[net].get();
+  CD_CHECK(n->kind() == CD_NET_UNET_OPENAI || n->kind() == CD_NET_UNET_HO, "net %d is not a U-Net", net);
+  return static_cast<UNet*>(n);
+}
+static VAE* get_vae(cd_handle h, int net) {
+  CD_CHECK(h && net >= 0 && net < (int)h->nets.size(), "bad net id %d", net);
+  Net* n = h->nets[net].get();
+  CD_CHECK(n->kind() == CD_NET_VAE_KL, "net %d is not a VAE", net);
+  return static_cast<VAE*>(n);
+}
+
+extern "C" {
+
+const char* cd_last_error(void) { return g_err.c_str(); }
+int cd_version(void) { return 100; }
+
+int cd_engine_create(void* hip_stream, size_t workspace_bytes, cd_handle* out) {
+  CD_API_BEGIN
+  CD_CHECK(out, "null out pointer");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  CD_CHECK(e == hipSuccess && ndev > 0, "no HIP device available (%s): the engine has no CPU fallback",
+           hipGetErrorString(e));
+  std::unique_ptr<cd_engine> h(new cd_engine());
+  h->st = (hipStream_t)hip_stream;
+  if (workspace_bytes < (256u << 20)) workspace_bytes = 256u << 20;
+  h->arena.init(workspace_bytes);
+  HIP_CHECK(hipMalloc((void**)&h->zeros, 4096));
+  HIP_CHECK(hipMemset(h->zeros, 0, 4096));
+  h->gn_partial_floats = (size_t)1 << 20;
+  HIP_CHECK(hipMalloc((void**)&h->gn_partial, h->gn_partial_floats * sizeof(float)));
+  *out = h.release();
+  CD_API_END
+}
+
+int cd_engine_destroy(cd_handle h) {
+  CD_API_BEGIN
+  if (h) {
+    (void)hipStreamSynchronize(h->st);
+    if (h->zeros) (void)hipFree(h->zeros);
+    if (h->gn_partial) (void)hipFree(h->gn_partial);
+    delete h;
+  }
+  CD_API_END
+}
+
+int cd_engine_workspace_high_water(cd_handle h, size_t* bytes) {
+  CD_API_BEGIN
+  CD_CHECK(h && bytes, "null argument");
+  *bytes = h->arena.high_water();
+  CD_API_END
+}
+
+int cd_net_create(cd_handle h, const cd_net_desc* d, int* net_id) {
+  CD_API_BEGIN
+  CD_CHECK(h && d && net_id, "null argument");
+  std::unique_ptr<Net> n;
+  switch (d->kind) {
+    case CD_NET_UNET_OPENAI: n = make_unet_openai(*d); break;
+    case CD_NET_UNET_HO: n = make_unet_ho(*d); break;
+    case CD_NET_VAE_KL: n = make_vae_kl(*d); break;
+    default: CD_CHECK(false, "unknown net kind %d", d->kind);
+  }
+  h->nets.push_back(std::move(n));
+  *net_id = (int)h->nets.size() - 1;
+  CD_API_END
+}
+
+int cd_net_param_count(cd_handle h, int net, int* n) {
+  CD_API_BEGIN
+  CD_CHECK(h && n && net >= 0 && net < (int)h->nets.size(), "bad argument");
+  *n = (int)h->nets[net]->params.decls().size();
+  CD_API_END
+}
+
+int cd_net_param_info(cd_handle h, int net, int index, char* name, int name_cap, int* ndim, int64_t shape[4]) {
+  CD_API_BEGIN
+  CD_CHECK(h && net >= 0 && net < (int)h->nets.size(), "bad net id");
+  auto& ds = h->nets[net]->params.decls();
+  CD_CHECK(index >= 0 && index < (int)ds.size(), "bad parameter index");
+  const ParamDecl& d = *ds[index];
+  if (name && name_cap > 0) { strncpy(name, d.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (ndim) *ndim = (int)d.shape.size();
+  if (shape) for (size_t i = 0; i < 4; ++i) shape[i] = i < d.shape.size() ? d.shape[i] : 1;
+  CD_API_END
+}
+
+int cd_net_load_param(cd_handle h, int net, const char* name, const float* data_host, int ndim,
+                      const int64_t* shape) {
+  CD_API_BEGIN
+  CD_CHECK(h && name && data_host && shape && net >= 0 && net < (int)h->nets.size(), "bad argument");
+  h->nets[net]->params.load(h->st, name, data_host, ndim, shape);
+  CD_API_END
+}
+
+int cd_net_missing_params(cd_handle h, int net, int* n_missing, char* first_name, int name_cap) {
+  CD_API_BEGIN
+  CD_CHECK(h && n_missing && net >= 0 && net < (int)h->nets.size(), "bad argument");
+  std::string first;
+  *n_missing = h->nets[net]->params.missing(&first);
+  if (first_name && name_cap > 0) { strncpy(first_name, first.c_str(), name_cap - 1); first_name[name_cap - 1] = 0; }
+  CD_API_END
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ helpers for the forward paths
+namespace {
+
+// ctx fp32 [B][L][Dc] -> bf16, optionally [uncond | cond] stacking for classifier-free guidance
+bf16_t* make_ctx(cd_engine* h, const float* a, const float* b, int B, int L, int Dc) {
+  const int nb = b ? 2 * B : B;
+  bf16_t* out = (bf16_t*)h->arena.alloc((size_t)nb * L * Dc * 2);
+  launch_nchw_to_nhwc(h->st, a, out, B * L, Dc, 1, Dc, 1.f, 0.f, 0);
+  if (b) launch_nchw_to_nhwc(h->st, b, out + (size_t)B * L * Dc, B * L, Dc, 1, Dc, 1.f, 0.f, 0);
+  return out;
+}
+
+struct Guidance {
+  bool cfg = false;       // run the 2B batch [uncond | cond]
+  const float* ctx_single = nullptr;
+};
+// ddim.py:550-559: scale==1 -> conditional only; scale==0 -> unconditional only; else CFG
+Guidance resolve_guidance(const float* ctx_c, const float* ctx_uc, float g) {
+  Guidance r;
+  if (!ctx_c && !ctx_uc) return r;
+  if (!ctx_uc || g == 1.0f) { r.ctx_single = ctx_c; return r; }
+  if (g == 0.0f) { r.ctx_single = ctx_uc; return r; }
+  r.cfg = true;
+  return r;
+}
+
+StepCoef* upload_coef(cd_engine* h, const cd_step_coef* host, int n) {
+  static_assert(sizeof(cd_step_coef) == sizeof(StepCoef), "coef ABI");
+  StepCoef* d = (StepCoef*)h->arena.alloc((size_t)n * sizeof(StepCoef));
+  HIP_CHECK(hipMemcpyAsync(d, host, (size_t)n * sizeof(StepCoef), hipMemcpyHostToDevice, h->st));
+  HIP_CHECK(hipStreamSynchronize(h->st));  // host table may be freed by the caller right after return
+  return d;
+}
+
+struct SamplerState {
+  UNet* u = nullptr;
+  int B = 0, Bn = 0, C = 0, HW = 0, cpad = 0, out_ld = 0;
+  bool cfg = false;
+  float g = 1.f;
+  float* xt = nullptr;
+  bf16_t* xin = nullptr;
+  float* eh = nullptr;
+  StepCoef* tab = nullptr;
+  EpsHat ehv;
+};
+
+SamplerState setup_sampler(cd_engine* h, int net, const float* ctx_c, const float* ctx_uc, int ctx_len,
+                           float guidance, int B) {
+  SamplerState s;
+  s.u = get_unet(h, net);
+  s.B = B; s.C = s.u->desc.in_channels; s.HW = s.u->image_size * s.u->image_size;
+  s.cpad = s.u->in_cpad; s.out_ld = s.u->out_channels;
+  Guidance gd = resolve_guidance(ctx_c, ctx_uc, guidance);
+  s.cfg = gd.cfg; s.g = guidance; s.Bn = s.cfg ? 2 * B : B;
+  Ctx c = h->ctx();
+  if (ctx_c || ctx_uc) {
+    const int Dc = s.u->desc.context_dim;
+    CD_CHECK(Dc > 0 && ctx_len > 0, "network has no cross-attention but a context was given");
+    bf16_t* cx = s.cfg ? make_ctx(h, ctx_uc, ctx_c, B, ctx_len, Dc) : make_ctx(h, gd.ctx_single, nullptr, B, ctx_len, Dc);
+    s.u->set_context(c, cx, s.Bn, ctx_len);
+  } else {
+    CD_CHECK(s.u->desc.context_dim <= 0 || !s.u->desc.use_spatial_transformer,
+             "network expects a cross-attention context");
+  }
+  s.xt = (float*)h->arena.alloc((size_t)B * s.C * s.HW * 4);
+  s.xin = (bf16_t*)h->arena.alloc((size_t)s.Bn * s.HW * s.cpad * 2);
+  HIP_CHECK(hipMemsetAsync(s.xin, 0, (size_t)s.Bn * s.HW * s.cpad * 2, h->st));
+  s.eh = (float*)h->arena.alloc((size_t)s.Bn * s.HW * s.out_ld * 4);
+  s.ehv.p = s.eh; s.ehv.sb = (int64_t)s.HW * s.out_ld; s.ehv.sc = 1; s.ehv.sp = s.out_ld;
+  s.ehv.cfg = s.cfg ? 1 : 0; s.ehv.g = guidance;
+  return s;
+}
+
+void run_unet(cd_engine* h, SamplerState& s, int step) {
+  Ctx c = h->ctx();
+  UNetIO io;
+  io.xin = s.xin; io.B = s.Bn; io.tab = s.tab; io.step = step; io.t_shared = true;
+  io.out = s.eh; io.out_ld = s.out_ld;
+  s.u->forward(c, io);
+}
+
+}  // namespace
+
+extern "C" {
+
+int cd_unet_forward(cd_handle h, int net, const float* x, const float* t, const float* ctx, int B,
+                    int ctx_len, float* eps_out) {
+  CD_API_BEGIN
+  UNet* u = get_unet(h, net);
+  CD_CHECK(x && t && eps_out && B > 0, "bad argument");
+  const size_t mk = h->arena.mark();
+  Ctx c = h->ctx();
+  const int C = u->desc.in_channels, HW = u->image_size * u->image_size, Co = u->out_channels;
+  if (ctx) {
+    const int Dc = u->desc.context_dim;
+    CD_CHECK(Dc > 0, "network has no cross-attention");
+    bf16_t* cx = make_ctx(h, ctx, nullptr, B, ctx_len, Dc);
+    u->set_context(c, cx, B, ctx_len);
+  }
+  bf16_t* xin = (bf16_t*)h->arena.alloc((size_t)B * HW * u->in_cpad * 2);
+  launch_nchw_to_nhwc(h->st, x, xin, B, C, HW, u->in_cpad, 1.f, 0.f, 0);
+  float* eh = (float*)h->arena.alloc((size_t)B * HW * Co * 4);
+  UNetIO io; io.xin = xin; io.B = B; io.t_explicit = t; io.t_shared = false; io.out = eh; io.out_ld = Co;
+  u->forward(c, io);
+  launch_nhwc_to_nchw(h->st, eh, 1, Co, eps_out, B, Co, HW, 1.f, 0.f);
+  h->arena.release(mk);
+  CD_API_END
+}
+
+int cd_vae_encode(cd_handle h, int net, const float* img, const float* noise, uint64_t seed, int B, int R,
+                  int sample, float scale, float* z0) {
+  CD_API_BEGIN
+  VAE* v = get_vae(h, net);
+  CD_CHECK(img && z0 && B > 0 && R % v->factor == 0, "bad argument");
+  const size_t mk = h->arena.mark();
+  Ctx c = h->ctx();
+  const int cin = v->desc.in_channels, cp = round_up(cin, 32), hl = R / v->factor;
+  bf16_t* xin = (bf16_t*)h->arena.alloc((size_t)B * R * R * cp * 2);
+  launch_nchw_to_nhwc(h->st, img, xin, B, cin, R * R, cp, 1.f, 0.f, 0);
+  const int mch = 2 * v->desc.embed_dim;
+  float* mom = (float*)h->arena.alloc((size_t)B * hl * hl * mch * 4);
+  v->encode_moments(c, xin, B, R, mom);
+  launch_posterior_sample(h->st, mom, mch, noise, seed, z0, B, v->desc.embed_dim, hl * hl, scale, sample ? 0 : 1);
+  h->arena.release(mk);
+  CD_API_END
+}
+
+int cd_vae_decode(cd_handle h, int net, const float* z0, int B, int hlat, float scale, float out_mul,
+                  float out_add, float* img) {
+  CD_API_BEGIN
+  VAE* v = get_vae(h, net);
+  CD_CHECK(z0 && img && B > 0 && hlat > 0, "bad argument");
+  const size_t mk = h->arena.mark();
+  Ctx c = h->ctx();
+  const int zc = v->desc.embed_dim, cp = round_up(zc, 32), R = hlat * v->factor, co = v->desc.out_channels;
+  bf16_t* zin = (bf16_t*)h->arena.alloc((size_t)B * hlat * hlat * cp * 2);
+  launch_nchw_to_nhwc(h->st, z0, zin, B, zc, hlat * hlat, cp, 1.0f / scale, 0.f, 0);  // z = 1/scale * z (ddpm.py:705)
+  float* o = (float*)h->arena.alloc((size_t)B * R * R * co * 4);
+  v->decode(c, zin, B, hlat, o);
+  launch_nhwc_to_nchw(h->st, o, 1, co, img, B, co, R * R, out_mul, out_add);
+  h->arena.release(mk);
+  CD_API_END
+}
+
+int cd_dpm_encode(cd_handle h, int net, int sched_kind, const float* x0, const float* ctx_c,
+                  const float* ctx_uc, int ctx_len, float guidance, int B, int K,
+                  const cd_step_coef* coef_host, const float* noise, uint64_t seed, int last_uses_x0,
+                  float* z_out) {
+  CD_API_BEGIN
+  CD_CHECK(h && x0 && coef_host && z_out && B > 0 && K > 0, "bad argument");
+  const size_t mk = h->arena.mark();
+  SamplerState s = setup_sampler(h, net, ctx_c, ctx_uc, ctx_len, guidance, B);
+  s.tab = upload_coef(h, coef_host, K + 1);
+  const int64_t chw = (int64_t)s.C * s.HW, n = (int64_t)B * chw;
+  const int64_t zbs = (int64_t)(K + 1) * chw;
+  launch_init_xt(h->st, x0, noise, seed, 0u, s.xt, z_out, zbs, B, s.C, s.HW, s.tab, K, s.xin, s.cpad,
+                 s.cfg ? 1 : 0);
+  for (int i = 0; i < K; ++i) {
+    const int k = K - 1 - i;
+    run_unet(h, s, k);
+    const int is_last = (last_uses_x0 && k == 0) ? 1 : 0;
+    const float* nz = (noise && !is_last) ? noise + (int64_t)(1 + i) * n : nullptr;
+    launch_encode_step(h->st, sched_kind, x0, s.xt, s.ehv, nz, seed, (uint32_t)(1 + i), z_out + (1 + i) * chw,
+                       zbs, B, s.C, s.HW, s.tab, nullptr, k, is_last, s.xin, s.cpad, s.cfg ? 1 : 0);
+  }
+  h->arena.release(mk);
+  CD_API_END
+}
+
+int cd_ddim_decode(cd_handle h, int net, int sched_kind, const float* z, int z_slots, int n_eps,
+                   const float* ctx_c, const float* ctx_uc, int ctx_len, float guidance, int B, int K,
+                   const cd_step_coef* coef_host, const float* noise_tail, uint64_t seed, float* x_out) {
+  CD_API_BEGIN
+  CD_CHECK(h && z && coef_host && x_out && B > 0 && K > 0 && n_eps <= z_slots - 1, "bad argument");
+  const size_t mk = h->arena.mark();
+  SamplerState s = setup_sampler(h, net, ctx_c, ctx_uc, ctx_len, guidance, B);
+  s.tab = upload_coef(h, coef_host, K);
+  const int64_t chw = (int64_t)s.C * s.HW, n = (int64_t)B * chw;
+  const int64_t zbs = (int64_t)z_slots * chw;
+  // x = z[:, 0]  (sd_wrapper:153; ddpm_ddim_wrapper.py:404)
+  HIP_CHECK(hipMemcpy2DAsync(s.xt, chw * 4, z, zbs * 4, chw * 4, B, hipMemcpyDeviceToDevice, h->st));
+  launch_nchw_to_nhwc(h->st, s.xt, s.xin, B, s.C, s.HW, s.cpad, 1.f, 0.f, s.cfg ? 1 : 0);
+  for (int i = 0; i < K; ++i) {
+    const int k = K - 1 - i;
+    run_unet(h, s, k);
+    const float* eps = (i < n_eps) ? z + (int64_t)(1 + i) * chw : nullptr;
+    const float* nz = (!eps && noise_tail) ? noise_tail + (int64_t)(i - n_eps) * n : nullptr;
+    launch_decode_step(h->st, sched_kind, s.xt, s.ehv, eps, zbs, nz, seed, (uint32_t)(0x1000 + i), B, s.C,
+                       s.HW, s.tab, nullptr, k, s.xin, s.cpad, s.cfg ? 1 : 0, nullptr);
+  }
+  HIP_CHECK(hipMemcpyAsync(x_out, s.xt, (size_t)n * 4, hipMemcpyDeviceToDevice, h->st));
+  h->arena.release(mk);
+  CD_API_END
+}
+
+int cd_pix_refine(cd_handle h, int net, int sched_kind, float* x, int B, int R, const cd_step_coef* coef_host,
+                  const float* noise, uint64_t seed) {
+  CD_API_BEGIN
+  CD_CHECK(h && x && coef_host && B > 0 && R > 0, "bad argument");
+  const size_t mk = h->arena.mark();
+  SamplerState s = setup_sampler(h, net, nullptr, nullptr, 0, 1.f, B);
+  s.tab = upload_coef(h, coef_host, R + 1);
+  const int64_t n = (int64_t)B * s.C * s.HW;
+  launch_init_xt(h->st, x, noise, seed, 0x2000u, s.xt, nullptr, 0, B, s.C, s.HW, s.tab, R, s.xin, s.cpad, 0);
+  for (int i = 0; i < R; ++i) {
+    const int k = R - 1 - i;
+    run_unet(h, s, k);
+    const float* nz = noise ? noise + (int64_t)(1 + i) * n : nullptr;
+    launch_decode_step(h->st, sched_kind, s.xt, s.ehv, nullptr, 0, nz, seed, (uint32_t)(0x2001 + i), B, s.C,
+                       s.HW, s.tab, nullptr, k, s.xin, s.cpad, 0, nullptr);
+  }
+  HIP_CHECK(hipMemcpyAsync(x, s.xt, (size_t)n * 4, hipMemcpyDeviceToDevice, h->st));
+  h->arena.release(mk);
+  CD_API_END
+}
+
+// ------------------------------------------------------------------ single-kernel entry points
+int cd_op_pack_conv_weight(cd_handle h, const float* w_host, int N, int Cin, int KH, int KW, int geglu,
+                           void** packed_dev, int* Npad, int* Cpad) {
+  CD_API_BEGIN
+  CD_CHECK(h && w_host && packed_dev, "bad argument");
+  static int counter = 0;
+  ConvW* c = h->op_params.new_conv(N, Cin, KH, KW, false, geglu != 0);
+  const std::string name = "op." + std::to_string(counter++);
+  h->op_params.conv_weight(name, c);
+  int64_t shape[4] = {N, Cin, KH, KW};
+  h->op_params.load(h->st, name, w_host, 4, shape);
+  *packed_dev = c;
+  if (Npad) *Npad = c->Npad;
+  if (Cpad) *Cpad = c->Cpad;
+  CD_API_END
+}
+
+int cd_op_free(cd_handle, void*) { return 0; }  // op weights live until the engine is destroyed
+
+int cd_op_conv2d(cd_handle h, const float* x0, int C0, const float* x1, int C1, int B, int H, int W,
+                 const void* packed_w, int N, int KH, int KW, int stride, int pad, int asym_pad, int up,
+                 const float* bias, const float* rowvec, const float* resid, int act, int tile, float* y) {
+  CD_API_BEGIN
+  CD_CHECK(h && x0 && packed_w && y, "bad argument");
+  const size_t mk = h->arena.mark();
+  Ctx c = h->ctx();
+  ConvW w = *(const ConvW*)packed_w;
+  CD_CHECK(w.N == N && w.KH == KH && w.KW == KW, "packed weight does not match the call");
+  w.b = const_cast<float*>(bias);
+  const int c0p = x1 ? C0 : round_up(C0, 32);
+  Act a0 = alloc_act(c, B, H, W, c0p);
+  launch_nchw_to_nhwc(h->st, x0, a0.p, B, C0, H * W, c0p, 1.f, 0.f, 0);
+  Act a1;
+  if (x1) {
+    a1 = alloc_act(c, B, H, W, C1);
+    launch_nchw_to_nhwc(h->st, x1, a1.p, B, C1, H * W, C1, 1.f, 0.f, 0);
+  }
+  ConvOpts o; o.stride = stride; o.pad = pad; o.asym = asym_pad != 0; o.up = up != 0; o.act = act; o.tile = tile;
+  o.out_f32 = true;
+  const int Hin = up ? 2 * H : H, Win = up ? 2 * W : W;
+  const int Ho = asym_pad ? (Hin + 1 - KH) / stride + 1 : (Hin + 2 * pad - KH) / stride + 1;
+  const int Wo = asym_pad ? (Win + 1 - KW) / stride + 1 : (Win + 2 * pad - KW) / stride + 1;
+  const int Nout = w.geglu ? N / 2 : N;
+  if (rowvec) { o.rowvec = rowvec; o.rowvec_ld = N; o.rows_per_vec = Ho * Wo; }
+  Act r;
+  if (resid) {
+    r = alloc_act(c, B, Ho, Wo, Nout);
+    launch_nchw_to_nhwc(h->st, resid, r.p, B, Nout, Ho * Wo, Nout, 1.f, 0.f, 0);
+    o.resid = &r;
+  }
+  Act out = conv_fwd(c, w, a0, x1 ? &a1 : nullptr, o);
+  launch_nhwc_to_nchw(h->st, out.p, 1, out.ld, y, B, Nout, Ho * Wo, 1.f, 0.f);
+  h->arena.release(mk);
+  CD_API_END
+}
+
+int cd_op_groupnorm(cd_handle h, const float* x, int B, int C, int H, int W, int G, float eps,
+                    const float* gamma, const float* beta, const float* film, int silu, float* y) {
+  CD_API_BEGIN
+  CD_CHECK(h && x && y && G == 32, "bad argument (G must be 32)");
+  const size_t mk = h->arena.mark();
+  Ctx c = h->ctx();
+  Act a = alloc_act(c, B, H, W, C);
+  launch_nchw_to_nhwc(h->st, x, a.p, B, C, H * W, C, 1.f, 0.f, 0);
+  GNW w; w.g = const_cast<float*>(gamma); w.b = const_cast<float*>(beta); w.C = C; w.eps = eps;
+  Act o = groupnorm_fwd(c, w, a, nullptr, silu != 0, film, film ? 2 * C : 0);
+  launch_nhwc_to_nchw(h->st, o.p, 0, o.ld, y, B, C, H * W, 1.f, 0.f);
+  h->arena.release(mk);
+  CD_API_END
+}
+
+int cd_op_layernorm(cd_handle h, const float* x, int rows, int C, const float* gamma, const float* beta,
+                    float eps, float* y) {
+  CD_API_BEGIN
+  CD_CHECK(h && x && y, "bad argument");
+  const size_t mk = h->arena.mark();
+  bf16_t* a = (bf16_t*)h->arena.alloc((size_t)rows * C * 2);
+  bf16_t* o = (bf16_t*)h->arena.alloc((size_t)rows * C * 2);
+  launch_nchw_to_nhwc(h->st, x, a, rows, C, 1, C, 1.f, 0.f, 0);
+  launch_layernorm(h->st, a, C, o, C, rows, C, gamma, beta, eps);
+  launch_nhwc_to_nchw(h->st, o, 0, C, y, rows, C, 1, 1.f, 0.f);
+  h->arena.release(mk);
+  CD_API_END
+}
+
+int cd_op_attention(cd_handle h, const float* q, const float* k, const float* v, int B, int H, int Tq,
+                    int Tk, int D, float scale, int use_transpose_kernel, float* o) {
+  CD_API_BEGIN
+  CD_CHECK(h && q && k && v && o, "bad argument");
+  (void)use_transpose_kernel;
+  const size_t mk = h->arena.mark();
+  const int C = H * D, Tpad = round_up(Tk, 64);
+  bf16_t* qb = (bf16_t*)h->arena.alloc((size_t)B * Tq * C * 2);
+  bf16_t* kb = (bf16_t*)h->arena.alloc((size_t)B * Tk * C * 2);
+  bf16_t* vb = (bf16_t*)h->arena.alloc((size_t)B * Tk * C * 2);
+  bf16_t* vt = (bf16_t*)h->arena.alloc((size_t)B * C * Tpad * 2);
+  bf16_t* ob = (bf16_t*)h->arena.alloc((size_t)B * Tq * C * 2);
+  launch_nchw_to_nhwc(h->st, q, qb, B * Tq, C, 1, C, 1.f, 0.f, 0);
+  launch_nchw_to_nhwc(h->st, k, kb, B * Tk, C, 1, C, 1.f, 0.f, 0);
+  launch_nchw_to_nhwc(h->st, v, vb, B * Tk, C, 1, C, 1.f, 0.f, 0);
+  launch_transpose_v(h->st, vb, C, (int64_t)Tk * C, vt, B, H, Tk, D, D, Tpad);
+  AttnParams p;
+  p.q = qb; p.k = kb; p.vt = vt; p.o = ob; p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.D = D;
+  p.ldq = C; p.ldk = C; p.ldo = C; p.q_bs = (int64_t)Tq * C; p.k_bs = (int64_t)Tk * C; p.o_bs = (int64_t)Tq * C;
+  p.vt_dpad = D; p.vt_tpad = Tpad; p.scale = scale;
+  launch_attention(h->st, p);
+  launch_nhwc_to_nchw(h->st, ob, 0, C, o, B * Tq, C, 1, 1.f, 0.f);
+  h->arena.release(mk);
+  CD_API_END
+}
+
+int cd_op_softmax_rows(cd_handle h, const float* s, int64_t rows, int cols, float* p) {
+  CD_API_BEGIN
+  CD_CHECK(h && s && p, "bad argument");
+  const size_t mk = h->arena.mark();
+  bf16_t* pb = (bf16_t*)h->arena.alloc((size_t)rows * cols * 2);
+  launch_softmax_rows(h->st, s, cols, pb, cols, rows, cols);
+  launch_nhwc_to_nchw(h->st, pb, 0, cols, p, (int)rows, cols, 1, 1.f, 0.f);
+  h->arena.release(mk);
+  CD_API_END
+}
+
+int cd_op_timestep_embedding(cd_handle h, const float* t, int B, int dim, int mode, float* out) {
+  CD_API_BEGIN
+  CD_CHECK(h && t && out, "bad argument");
+  launch_timestep_embedding(h->st, nullptr, nullptr, 0, t, out, B, dim, mode);
+  CD_API_END
+}
+
+int cd_op_sched_step(cd_handle h, int mode, int sched_kind, const cd_step_coef* coef_host, const float* x0,
+                     float* xt, const float* eps_hat, int cfg, float guidance, const float* noise,
+                     const float* eps_in, int is_last, int B, int C, int HW, float* z_slot) {
+  CD_API_BEGIN
+  CD_CHECK(h && coef_host && xt, "bad argument");
+  const size_t mk = h->arena.mark();
+  StepCoef* tab = upload_coef(h, coef_host, 1);
+  const int64_t chw = (int64_t)C * HW;
+  EpsHat eh; eh.p = eps_hat; eh.sb = chw; eh.sc = HW; eh.sp = 1; eh.cfg = cfg; eh.g = guidance;  // NCHW view
+  if (mode == 0) {
+    launch_init_xt(h->st, x0, noise, 0, 0, xt, z_slot, chw, B, C, HW, tab, 0, nullptr, 0, 0);
+  } else if (mode == 1) {
+    launch_encode_step(h->st, sched_kind, x0, xt, eh, noise, 0, 0, z_slot, chw, B, C, HW, tab, nullptr, 0,
+                       is_last, nullptr, 0, 0);
+  } else {
+    launch_decode_step(h->st, sched_kind, xt, eh, eps_in, chw, noise, 0, 0, B, C, HW, tab, nullptr, 0, nullptr,
+                       0, 0, nullptr);
+  }
+  HIP_CHECK(hipStreamSynchronize(h->st));
+  h->arena.release(mk);
+  CD_API_END
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ hardware layout probes
+namespace {
+__global__ void k_probe_mfma(float* out) {
+  // which=0: D = A.B with A[i][0] = i+1 (else 0), B[0][j] = 1  -> D[i][j] = i+1 (row map)
+  //          then A[i][0] = 1, B[0][j] = j+1                   -> D[i][j] = j+1 (col map)
+  const int lane = threadIdx.x & 63;
+  bf16x8 a = {0, 0, 0, 0, 0, 0, 0, 0}, b = {0, 0, 0, 0, 0, 0, 0, 0};
+  f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (lane < 32) { a[0] = (short)f2bf((float)(lane + 1)); b[0] = (short)f2bf(1.0f); }
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) out[lane * 16 + r] = acc[r];
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (lane < 32) { a[0] = (short)f2bf(1.0f); b[0] = (short)f2bf((float)(lane + 1)); }
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) out[1024 + lane * 16 + r] = acc[r];
+  // k-slot check: A[i][k] = 1 for all i, only k = kk set; B[kk][j] = kk+1 -> D = sum over matching k
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int j = 0; j < 8; ++j) { a[j] = (short)f2bf(1.0f); b[j] = (short)f2bf((float)(8 * (lane >> 5) + j + 1)); }
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) out[2048 + lane * 16 + r] = acc[r];  // expect 1+2+...+16 = 136
+}
+__global__ void k_probe_tr(float* out) {
+  __shared__ __attribute__((aligned(16))) bf16_t lds[256];
+  const int lane = threadIdx.x & 63;
+  for (int i = lane; i < 256; i += 64) lds[i] = f2bf((float)i);
+  __syncthreads();
+  uint2 v;
+  const unsigned addr = (unsigned)(size_t)(lds) + lane * 8;
+  asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  out[lane * 4 + 0] = bf2f((bf16_t)(v.x & 0xffff));
+  out[lane * 4 + 1] = bf2f((bf16_t)(v.x >> 16));
+  out[lane * 4 + 2] = bf2f((bf16_t)(v.y & 0xffff));
+  out[lane * 4 + 3] = bf2f((bf16_t)(v.y >> 16));
+}
+}  // namespace
+
+extern "C" int cd_op_probe(cd_handle h, int which, const void* in, void* out, size_t n) {
+  CD_API_BEGIN
+  (void)in;
+  CD_CHECK(h && out, "bad argument");
+  if (which == 0) {
+    CD_CHECK(n >= 3072 * sizeof(float), "probe 0 needs 3072 floats");
+    hipLaunchKernelGGL(k_probe_mfma, dim3(1), dim3(64), 0, h->st, (float*)out);
+  } else if (which == 1) {
+    CD_CHECK(n >= 256 * sizeof(float), "probe 1 needs 256 floats");
+    hipLaunchKernelGGL(k_probe_tr, dim3(1), dim3(64), 0, h->st, (float*)out);
+  } else {
+    CD_CHECK(false, "unknown probe %d", which);
+  }
+  CD_API_END
+}

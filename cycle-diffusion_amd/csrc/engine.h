@@ -1,0 +1,190 @@
+// Engine core: device arena, parameter store keyed by the reference's state_dict names, and the
+// network executors (static launch schedules over the kernels in kernels.h).
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+#include "../../include/cyclediff.h"
+
+namespace cd {
+
+// ------------------------------------------------------------------ device memory
+// Stack-discipline bump allocator over one slab (sized for 288 GB parts: activations of a whole
+// forward pass stay resident; temporaries of a block are released at block exit so the hot
+// working set keeps re-using the same lines of the 256 MiB Infinity Cache).
+class Arena {
+ public:
+  ~Arena();
+  void init(size_t bytes);
+  void* alloc(size_t bytes);
+  size_t mark() const { return off_; }
+  void release(size_t m) { off_ = m; }
+  void reset() { off_ = 0; }
+  size_t capacity() const { return cap_; }
+  size_t high_water() const { return high_; }
+ private:
+  char* base_ = nullptr;
+  size_t cap_ = 0, off_ = 0, high_ = 0;
+};
+
+struct Act {  // NHWC bf16 activation view
+  bf16_t* p = nullptr;
+  int B = 0, H = 0, W = 0, C = 0;
+  int ld = 0;  // pixel stride (elements)
+  int64_t rows() const { return (int64_t)B * H * W; }
+};
+
+// ------------------------------------------------------------------ parameters
+struct ConvW {  // packed conv / linear weight: bf16 [Npad][KH*KW*Cpad], fp32 bias[N]
+  bf16_t* w = nullptr;
+  float* b = nullptr;
+  int N = 0, Cin = 0, Cpad = 0, KH = 1, KW = 1, Npad = 0;
+  bool geglu = false;
+  int Ktot() const { return KH * KW * Cpad; }
+};
+
+struct PackTarget {
+  enum Kind { MATRIX_BF16, VECTOR_F32, MATRIX_F32 } kind;
+  // MATRIX_BF16: rows [dst_row0, dst_row0+rows) of dst ConvW come from source rows
+  //   src_base + (j/grp)*grp_stride + j%grp, j in [0, rows)
+  ConvW* conv = nullptr;
+  int dst_row0 = 0, rows = 0, src_base = 0, grp = 0, grp_stride = 0;
+  // VECTOR_F32 / MATRIX_F32: dst[dst_off + j(*K)] with the same row mapping; geglu interleave
+  float* fdst = nullptr;
+  int dst_off = 0, K = 1;
+  bool geglu = false;
+  int geglu_N = 0;
+};
+
+struct ParamDecl {
+  std::string name;
+  std::vector<int64_t> shape;  // reference (torch) shape
+  std::vector<PackTarget> targets;
+  bool loaded = false;
+};
+
+class ParamStore {
+ public:
+  ~ParamStore();
+  // allocate packed storage
+  ConvW* new_conv(int N, int Cin, int KH, int KW, bool bias, bool geglu = false);
+  float* new_vec(int n, float init = 0.f);
+  // declare reference tensors and where their rows go
+  ParamDecl& declare(const std::string& name, std::vector<int64_t> shape);
+  void conv_weight(const std::string& name, ConvW* c);  // whole tensor -> whole ConvW
+  void conv_bias(const std::string& name, ConvW* c);
+  void conv_rows(const std::string& name, std::vector<int64_t> shape, ConvW* c, int dst_row0, int rows,
+                 int src_base, int grp, int grp_stride);
+  void bias_rows(const std::string& name, int64_t n_total, float* dst, int dst_off, int rows, int src_base,
+                 int grp, int grp_stride);
+  void vec(const std::string& name, float* dst, int n);
+  void mat_f32(const std::string& name, float* dst, int N, int K, int dst_row0 = 0);
+
+  void load(hipStream_t st, const std::string& name, const float* host, int ndim, const int64_t* shape);
+  int missing(std::string* first = nullptr) const;
+  const std::vector<std::unique_ptr<ParamDecl>>& decls() const { return decls_; }
+  size_t device_bytes() const { return dev_bytes_; }
+ private:
+  std::vector<std::unique_ptr<ParamDecl>> decls_;
+  std::map<std::string, ParamDecl*> by_name_;
+  std::vector<std::unique_ptr<ConvW>> convs_;
+  std::vector<void*> allocs_;
+  float* staging_ = nullptr;
+  size_t staging_bytes_ = 0;
+  size_t dev_bytes_ = 0;
+  void* dmalloc(size_t bytes);
+};
+
+// ------------------------------------------------------------------ execution context
+struct Ctx {
+  hipStream_t st = nullptr;
+  Arena* arena = nullptr;
+  const bf16_t* zeros = nullptr;
+  float* gn_partial = nullptr;  // [B][S][G][2] scratch, sized for the largest GroupNorm
+  size_t gn_partial_floats = 0;
+};
+
+// shared building blocks -------------------------------------------------------------------
+struct ConvOpts {
+  int stride = 1;
+  int pad = 1;          // symmetric top/left padding (bottom/right implied by the output size)
+  bool asym = false;    // VAE/Ho Downsample: F.pad(x,(0,1,0,1)) + stride-2 conv (model.py:72-76)
+  bool up = false;      // nearest x2 before the conv
+  const float* rowvec = nullptr; int rowvec_ld = 0; int rows_per_vec = 1;
+  const Act* resid = nullptr;
+  int act = ACT_NONE;
+  float alpha = 1.f;
+  bool out_f32 = false;
+  void* out = nullptr;  // optional preallocated output
+  int out_ld = 0;
+  int tile = 0;
+};
+Act alloc_act(Ctx& c, int B, int H, int W, int C);
+// y = conv(x [| x2]) with the fused epilogue; returns the output view (bf16 unless out_f32)
+Act conv_fwd(Ctx& c, const ConvW& w, const Act& x, const Act* x2, const ConvOpts& o);
+
+struct GNW { float* g = nullptr; float* b = nullptr; int C = 0; float eps = 1e-5f; };
+Act groupnorm_fwd(Ctx& c, const GNW& w, const Act& x, const Act* x2, bool silu, const float* film = nullptr,
+                  int film_ld = 0);
+struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; };
+Act layernorm_fwd(Ctx& c, const LNW& w, const Act& x);
+
+// multi-head attention on token-major activations; vt is [B][H*D][Tpad]
+Act attention_fwd(Ctx& c, const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* vt, int B,
+                  int H, int Tq, int Tk, int Tpad, int D, float scale, int Himg, int Wimg);
+
+// ------------------------------------------------------------------ networks
+class Net {
+ public:
+  virtual ~Net() {}
+  ParamStore params;
+  cd_net_desc desc;
+  virtual int kind() const = 0;
+};
+
+struct TimeEmb {  // shared by all U-Nets: sinusoid -> MLP -> per-ResBlock projections in one launch
+  int mode = 0, dim = 0, hidden = 0;
+  float *w0 = nullptr, *b0 = nullptr, *w1 = nullptr, *b1 = nullptr;  // fp32 [hidden][dim], [hidden][hidden]
+  float* proj_w = nullptr; float* proj_b = nullptr;                   // fused emb_layers: [proj_total][hidden]
+  int proj_total = 0;
+};
+
+struct UNetIO {
+  const bf16_t* xin = nullptr;   // NHWC bf16 [B][H][W][Cpad_in]
+  int B = 0;
+  // timestep source: either a schedule table row (device step counter or immediate) or explicit floats
+  const StepCoef* tab = nullptr; const int* step_ptr = nullptr; int step = 0;
+  const float* t_explicit = nullptr;  // [B] device, or null
+  bool t_shared = true;               // all samples share one timestep -> embed once
+  float* out = nullptr;               // fp32 [B*H*W][out_ld]
+  int out_ld = 0;
+};
+
+class UNet : public Net {
+ public:
+  virtual void forward(Ctx& c, const UNetIO& io) = 0;
+  // cross-attention K / V^T of the context are step-invariant: computed once per call
+  virtual void set_context(Ctx& c, const bf16_t* ctx, int B, int L) { (void)c; (void)ctx; (void)B; (void)L; }
+  int in_cpad = 32;
+  int out_channels = 0;
+  int image_size = 0;
+  virtual size_t workspace_hint(int B) const = 0;
+};
+
+std::unique_ptr<UNet> make_unet_openai(const cd_net_desc& d);
+std::unique_ptr<UNet> make_unet_ho(const cd_net_desc& d);
+
+class VAE : public Net {
+ public:
+  int kind() const override { return CD_NET_VAE_KL; }
+  virtual void encode_moments(Ctx& c, const bf16_t* img_nhwc, int B, int R, float* moments) = 0;  // fp32 [B*h*w][2*zc]
+  virtual void decode(Ctx& c, const bf16_t* z_nhwc, int B, int h, float* img) = 0;                 // fp32 [B*R*R][3]
+  int z_channels = 4, factor = 8;
+};
+std::unique_ptr<VAE> make_vae_kl(const cd_net_desc& d);
+
+}  // namespace cd

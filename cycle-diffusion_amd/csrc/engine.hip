@@ -1,0 +1,279 @@
+// Arena, parameter store and the shared building blocks (conv / norm / attention wrappers).
+#include "engine.h"
+
+#include <string.h>
+
+namespace cd {
+
+// ------------------------------------------------------------------ Arena
+Arena::~Arena() { if (base_) (void)hipFree(base_); }
+void Arena::init(size_t bytes) {
+  if (base_) { (void)hipFree(base_); base_ = nullptr; }
+  HIP_CHECK(hipMalloc((void**)&base_, bytes));
+  cap_ = bytes; off_ = 0; high_ = 0;
+}
+void* Arena::alloc(size_t bytes) {
+  size_t a = (off_ + 255) & ~(size_t)255;
+  CD_CHECK(a + bytes <= cap_, "workspace arena exhausted: need %zu more bytes (capacity %zu); "
+           "create the engine with a larger workspace", a + bytes - cap_, cap_);
+  off_ = a + bytes;
+  if (off_ > high_) high_ = off_;
+  return base_ + a;
+}
+
+// ------------------------------------------------------------------ ParamStore
+ParamStore::~ParamStore() {
+  for (void* p : allocs_) (void)hipFree(p);
+  if (staging_) (void)hipFree(staging_);
+}
+void* ParamStore::dmalloc(size_t bytes) {
+  void* p = nullptr;
+  HIP_CHECK(hipMalloc(&p, bytes < 256 ? 256 : bytes));
+  HIP_CHECK(hipMemset(p, 0, bytes < 256 ? 256 : bytes));
+  allocs_.push_back(p);
+  dev_bytes_ += bytes;
+  return p;
+}
+ConvW* ParamStore::new_conv(int N, int Cin, int KH, int KW, bool bias, bool geglu) {
+  convs_.emplace_back(new ConvW());
+  ConvW* c = convs_.back().get();
+  c->N = N; c->Cin = Cin; c->KH = KH; c->KW = KW; c->geglu = geglu;
+  c->Cpad = round_up(Cin, 32);
+  c->Npad = round_up(N, 128);
+  c->w = (bf16_t*)dmalloc((size_t)c->Npad * c->Ktot() * sizeof(bf16_t));
+  if (bias) c->b = (float*)dmalloc((size_t)c->Npad * sizeof(float));
+  return c;
+}
+float* ParamStore::new_vec(int n, float init) {
+  float* p = (float*)dmalloc((size_t)n * sizeof(float));
+  if (init != 0.f) {
+    std::vector<float> h(n, init);
+    HIP_CHECK(hipMemcpy(p, h.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return p;
+}
+ParamDecl& ParamStore::declare(const std::string& name, std::vector<int64_t> shape) {
+  auto it = by_name_.find(name);
+  if (it != by_name_.end()) {
+    CD_CHECK(it->second->shape == shape, "parameter %s declared twice with different shapes", name.c_str());
+    return *it->second;
+  }
+  decls_.emplace_back(new ParamDecl());
+  ParamDecl* d = decls_.back().get();
+  d->name = name; d->shape = std::move(shape);
+  by_name_[name] = d;
+  return *d;
+}
+void ParamStore::conv_weight(const std::string& name, ConvW* c) {
+  std::vector<int64_t> shape;
+  if (c->KH == 1 && c->KW == 1) shape = {c->N, c->Cin};  // Linear or 1x1 conv: accept both ranks at load
+  else shape = {c->N, c->Cin, c->KH, c->KW};
+  ParamDecl& d = declare(name, shape);
+  PackTarget t; t.kind = PackTarget::MATRIX_BF16; t.conv = c; t.dst_row0 = 0; t.rows = c->N;
+  t.src_base = 0; t.grp = c->N; t.grp_stride = 0; t.geglu = c->geglu;
+  d.targets.push_back(t);
+}
+void ParamStore::conv_bias(const std::string& name, ConvW* c) {
+  CD_CHECK(c->b, "conv %s has no bias storage", name.c_str());
+  ParamDecl& d = declare(name, {c->N});
+  PackTarget t; t.kind = PackTarget::VECTOR_F32; t.fdst = c->b; t.dst_off = 0; t.rows = c->N;
+  t.src_base = 0; t.grp = c->N; t.grp_stride = 0; t.geglu = c->geglu; t.geglu_N = c->N;
+  d.targets.push_back(t);
+}
+void ParamStore::conv_rows(const std::string& name, std::vector<int64_t> shape, ConvW* c, int dst_row0,
+                           int rows, int src_base, int grp, int grp_stride) {
+  ParamDecl& d = declare(name, std::move(shape));
+  PackTarget t; t.kind = PackTarget::MATRIX_BF16; t.conv = c; t.dst_row0 = dst_row0; t.rows = rows;
+  t.src_base = src_base; t.grp = grp; t.grp_stride = grp_stride;
+  d.targets.push_back(t);
+}
+void ParamStore::bias_rows(const std::string& name, int64_t n_total, float* dst, int dst_off, int rows,
+                           int src_base, int grp, int grp_stride) {
+  ParamDecl& d = declare(name, {n_total});
+  PackTarget t; t.kind = PackTarget::VECTOR_F32; t.fdst = dst; t.dst_off = dst_off; t.rows = rows;
+  t.src_base = src_base; t.grp = grp; t.grp_stride = grp_stride;
+  d.targets.push_back(t);
+}
+void ParamStore::vec(const std::string& name, float* dst, int n) {
+  bias_rows(name, n, dst, 0, n, 0, n, 0);
+}
+void ParamStore::mat_f32(const std::string& name, float* dst, int N, int K, int dst_row0) {
+  ParamDecl& d = declare(name, {N, K});
+  PackTarget t; t.kind = PackTarget::MATRIX_F32; t.fdst = dst; t.dst_off = dst_row0; t.rows = N; t.K = K;
+  t.src_base = 0; t.grp = N; t.grp_stride = 0;
+  d.targets.push_back(t);
+}
+
+// repack with a row map: dst row j <- src row src_base + (j/grp)*grp_stride + j%grp
+__global__ void k_pack_rows(const float* __restrict__ w, bf16_t* __restrict__ out, int rows, int Cin,
+                            int KH, int KW, int Cpad, int dst_row0, int src_base, int grp,
+                            int grp_stride, int geglu, int Ntot) {
+  const int64_t total = (int64_t)rows * KH * KW * Cpad;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cpad);
+    int64_t t = i / Cpad;
+    const int s = (int)(t % KW); t /= KW;
+    const int r = (int)(t % KH); t /= KH;
+    const int j = (int)t;  // destination row (relative)
+    int jj = j;
+    if (geglu) {  // packed row j: blocks of 64 = [32 value | 32 gate]
+      const int blk = j / 64, within = j % 64;
+      jj = (within < 32) ? blk * 32 + within : Ntot / 2 + blk * 32 + (within - 32);
+    }
+    const int src = src_base + (jj / grp) * grp_stride + (jj % grp);
+    float v = 0.f;
+    if (c < Cin) v = w[(((int64_t)src * Cin + c) * KH + r) * KW + s];
+    out[((int64_t)(dst_row0 + j) * KH * KW + (int64_t)r * KW + s) * Cpad + c] = f2bf(v);
+  }
+}
+
+void ParamStore::load(hipStream_t st, const std::string& name, const float* host, int ndim,
+                      const int64_t* shape) {
+  auto it = by_name_.find(name);
+  CD_CHECK(it != by_name_.end(), "unknown parameter name '%s'", name.c_str());
+  ParamDecl& d = *it->second;
+  int64_t n = 1, nd = 1;
+  for (int i = 0; i < ndim; ++i) n *= shape[i];
+  for (auto s : d.shape) nd *= s;
+  // accept [N,C] for [N,C,1,1] / [N,C,1] (conv1d / 1x1 conv stored as linear and vice versa)
+  bool ok = (n == nd) && ndim >= 1 && shape[0] == d.shape[0];
+  if (ok && d.shape.size() >= 2 && ndim >= 2) ok = (shape[1] == d.shape[1]);
+  CD_CHECK(ok, "parameter %s: shape mismatch (got %lld elements, ndim %d; expected %lld)", name.c_str(),
+           (long long)n, ndim, (long long)nd);
+  const size_t bytes = (size_t)n * sizeof(float);
+  if (bytes > staging_bytes_) {
+    if (staging_) HIP_CHECK(hipFree(staging_));
+    staging_bytes_ = bytes < (1u << 20) ? (1u << 20) : bytes;
+    HIP_CHECK(hipMalloc((void**)&staging_, staging_bytes_));
+  }
+  HIP_CHECK(hipStreamSynchronize(st));
+  HIP_CHECK(hipMemcpy(staging_, host, bytes, hipMemcpyHostToDevice));
+  for (const PackTarget& t : d.targets) {
+    if (t.kind == PackTarget::MATRIX_BF16) {
+      const ConvW* c = t.conv;
+      const int64_t total = (int64_t)t.rows * c->KH * c->KW * c->Cpad;
+      int grid = (int)((total + 255) / 256);
+      if (grid > 8192) grid = 8192;
+      hipLaunchKernelGGL(k_pack_rows, dim3(grid), dim3(256), 0, st, staging_, c->w, t.rows, c->Cin, c->KH,
+                         c->KW, c->Cpad, t.dst_row0, t.src_base, t.grp, t.grp_stride, t.geglu ? 1 : 0,
+                         c->N);
+    } else {
+      // small: map on the host
+      const int K = (t.kind == PackTarget::MATRIX_F32) ? t.K : 1;
+      std::vector<float> tmp((size_t)t.rows * K);
+      for (int j = 0; j < t.rows; ++j) {
+        int jj = j;
+        if (t.geglu) {
+          const int blk = j / 64, within = j % 64;
+          jj = (within < 32) ? blk * 32 + within : t.geglu_N / 2 + blk * 32 + (within - 32);
+        }
+        const int src = t.src_base + (jj / t.grp) * t.grp_stride + (jj % t.grp);
+        memcpy(&tmp[(size_t)j * K], host + (size_t)src * K, (size_t)K * sizeof(float));
+      }
+      HIP_CHECK(hipMemcpy(t.fdst + (size_t)t.dst_off * K, tmp.data(), tmp.size() * sizeof(float),
+                          hipMemcpyHostToDevice));
+    }
+  }
+  HIP_CHECK(hipStreamSynchronize(st));
+  d.loaded = true;
+}
+
+int ParamStore::missing(std::string* first) const {
+  int n = 0;
+  for (auto& d : decls_)
+    if (!d->loaded) {
+      if (n == 0 && first) *first = d->name;
+      ++n;
+    }
+  return n;
+}
+
+// ------------------------------------------------------------------ building blocks
+Act alloc_act(Ctx& c, int B, int H, int W, int C) {
+  Act a; a.B = B; a.H = H; a.W = W; a.C = C; a.ld = C;
+  a.p = (bf16_t*)c.arena->alloc((size_t)B * H * W * C * sizeof(bf16_t));
+  return a;
+}
+
+Act conv_fwd(Ctx& c, const ConvW& w, const Act& x, const Act* x2, const ConvOpts& o) {
+  ConvGemmParams p;
+  p.src0 = x.p; p.C0 = round_up(x.C, 32); p.ld0 = x.ld;
+  if (x2) {
+    CD_CHECK(x2->B == x.B && x2->H == x.H && x2->W == x.W, "conv: concat sources differ in shape");
+    p.src1 = x2->p; p.C1 = x2->C; p.ld1 = x2->ld;
+    CD_CHECK(x.C % 32 == 0 && x2->C % 32 == 0, "conv: concat channels must be multiples of 32");
+  }
+  CD_CHECK(p.C0 + p.C1 == w.Cpad, "conv: input channels %d+%d do not match weight Cpad %d", p.C0, p.C1, w.Cpad);
+  CD_CHECK(x.ld >= p.C0, "conv: source row shorter than padded channel count");
+  p.B = x.B; p.Hs = x.H; p.Ws = x.W; p.up = o.up ? 1 : 0;
+  p.Hin = o.up ? x.H * 2 : x.H; p.Win = o.up ? x.W * 2 : x.W;
+  p.KH = w.KH; p.KW = w.KW; p.stride = o.stride;
+  if (o.asym) { p.pad_t = 0; p.pad_l = 0; p.Hout = (p.Hin + 1 - w.KH) / o.stride + 1; p.Wout = (p.Win + 1 - w.KW) / o.stride + 1; }
+  else {
+    p.pad_t = o.pad; p.pad_l = o.pad;
+    p.Hout = (p.Hin + 2 * o.pad - w.KH) / o.stride + 1;
+    p.Wout = (p.Win + 2 * o.pad - w.KW) / o.stride + 1;
+  }
+  p.M = x.B * p.Hout * p.Wout;
+  p.wgt = w.w; p.Ktot = w.Ktot(); p.N = w.N;
+  p.alpha = o.alpha; p.bias = w.b;
+  p.rowvec = o.rowvec; p.rowvec_ld = o.rowvec_ld; p.rows_per_vec = o.rows_per_vec;
+  p.act = w.geglu ? ACT_GEGLU : o.act;
+  const int Nout = w.geglu ? w.N / 2 : w.N;
+  Act y; y.B = x.B; y.H = p.Hout; y.W = p.Wout; y.C = Nout;
+  if (o.out) { y.p = (bf16_t*)o.out; y.ld = o.out_ld; }
+  else {
+    y.ld = Nout;
+    y.p = (bf16_t*)c.arena->alloc((size_t)p.M * Nout * (o.out_f32 ? 4 : 2));
+  }
+  if (o.resid) {
+    CD_CHECK(o.resid->rows() == p.M && o.resid->C == Nout, "conv: residual shape mismatch");
+    p.resid = o.resid->p; p.resid_ld = o.resid->ld;
+  }
+  p.out = y.p; p.out_ld = y.ld; p.out_f32 = o.out_f32 ? 1 : 0;
+  p.zeros = c.zeros; p.tile = o.tile;
+  launch_conv_gemm(c.st, p);
+  return y;
+}
+
+Act groupnorm_fwd(Ctx& c, const GNW& w, const Act& x, const Act* x2, bool silu, const float* film,
+                  int film_ld) {
+  GroupNormParams p;
+  p.x = x.p; p.C0 = x.C; p.ld0 = x.ld;
+  if (x2) { p.x1 = x2->p; p.C1 = x2->C; p.ld1 = x2->ld; }
+  const int C = p.C0 + p.C1;
+  CD_CHECK(C == w.C, "groupnorm: channels %d != weight %d", C, w.C);
+  p.B = x.B; p.HW = x.H * x.W; p.G = 32; p.eps = w.eps; p.gamma = w.g; p.beta = w.b;
+  p.film = film; p.film_ld = film_ld; p.silu = silu ? 1 : 0;
+  Act y = alloc_act(c, x.B, x.H, x.W, C);
+  p.y = y.p;
+  p.S = groupnorm_slabs(p.B, p.HW, C);
+  CD_CHECK((size_t)p.B * p.S * p.G * 2 <= c.gn_partial_floats, "groupnorm: partial workspace too small");
+  p.partial = c.gn_partial;
+  launch_groupnorm(c.st, p);
+  return y;
+}
+
+Act layernorm_fwd(Ctx& c, const LNW& w, const Act& x) {
+  CD_CHECK(x.C == w.C, "layernorm: channels");
+  Act y = alloc_act(c, x.B, x.H, x.W, x.C);
+  launch_layernorm(c.st, x.p, x.ld, y.p, y.ld, (int)x.rows(), x.C, w.g, w.b, 1e-5f);
+  return y;
+}
+
+Act attention_fwd(Ctx& c, const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* vt, int B,
+                  int H, int Tq, int Tk, int Tpad, int D, float scale, int Himg, int Wimg) {
+  Act o = alloc_act(c, B, Himg, Wimg, H * D);
+  AttnParams p;
+  p.q = q; p.k = k; p.vt = vt; p.o = o.p;
+  p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.D = D;
+  p.ldq = ldq; p.ldk = ldk; p.ldo = o.ld;
+  p.q_bs = (int64_t)Tq * ldq; p.k_bs = (int64_t)Tk * ldk; p.o_bs = (int64_t)Tq * o.ld;
+  p.vt_dpad = D; p.vt_tpad = Tpad;
+  p.scale = scale;
+  launch_attention(c.st, p);
+  return o;
+}
+
+}  // namespace cd

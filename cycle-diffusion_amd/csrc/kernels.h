@@ -1,0 +1,155 @@
+// Launcher declarations for the hand-written gfx950 kernels (implementation: *.hip in this dir).
+#pragma once
+#include "common.h"
+
+namespace cd {
+
+// ---------------------------------------------------------------- scheduler (sched.hip)
+// Per-step scalar coefficients, evaluated on the host in fp32 in the reference's operation
+// order (ddim.py:570-579). DDIM-eta form:
+//   sa=sqrt(a_t) s1a=sqrt(1-a_t) sap=sqrt(a_prev) dirc=sqrt(1-a_prev-sigma^2) sigma r=sqrt(1-a_t)
+// DDPM form (pixel 'ddpm'): see sched.hip k_encode_step_ddpm.
+struct StepCoef {
+  float sa, s1a, sap, dirc, sigma, r, t_mask;
+  int t;  // integer timestep fed to the U-Net
+};
+enum { SCHED_DDIM = 0, SCHED_DDPM = 1 };
+
+struct EpsHat {  // network output view: element (b,c,p) at p[b*sb + c*sc + p*sp]
+  const float* p;
+  int64_t sb, sc, sp;
+  int cfg;   // 1: batch is [uncond B | cond B], combine with guidance scale g
+  float g;
+};
+
+void launch_init_xt(hipStream_t st, const float* x0, const float* noise, uint64_t seed,
+                    uint32_t stream, float* xt, float* z, int64_t z_bstride, int B, int C, int HW,
+                    const StepCoef* tab, int step, bf16_t* xin, int xin_cpad, int cfg_dup);
+void launch_encode_step(hipStream_t st, int kind, const float* x0, float* xt, const EpsHat& eh,
+                        const float* noise, uint64_t seed, uint32_t stream, float* z,
+                        int64_t z_bstride, int B, int C, int HW, const StepCoef* tab,
+                        const int* step_ptr, int step, int is_last, bf16_t* xin, int xin_cpad,
+                        int cfg_dup_next);
+void launch_decode_step(hipStream_t st, int kind, float* x, const EpsHat& eh, const float* eps,
+                        int64_t eps_bstride, const float* noise, uint64_t seed, uint32_t stream,
+                        int B, int C, int HW, const StepCoef* tab, const int* step_ptr, int step,
+                        bf16_t* xin, int xin_cpad, int cfg_dup_next, float* x0_pred);
+void launch_set_int(hipStream_t st, int* p, int v);
+void launch_add_int(hipStream_t st, int* p, int d);
+
+// ---------------------------------------------------------------- implicit-GEMM conv / GEMM (conv_gemm.hip)
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_GEGLU = 3 };
+
+struct ConvGemmParams {
+  // A operand: activations, NHWC bf16; optional second source = channel concat (th.cat, openaimodel.py:736)
+  const bf16_t* src0 = nullptr;
+  const bf16_t* src1 = nullptr;
+  int C0 = 0, C1 = 0;        // channels taken from each source (multiples of 32)
+  int ld0 = 0, ld1 = 0;      // pixel stride in elements
+  int B = 1, Hs = 1, Ws = 1; // stored spatial dims of the sources
+  int up = 0;                // 1: nearest x2 upsample folded into the gather (F.interpolate, openaimodel.py:115)
+  int Hin = 1, Win = 1;      // logical input dims (= 2*Hs when up)
+  int KH = 1, KW = 1, stride = 1, pad_t = 0, pad_l = 0;
+  int Hout = 1, Wout = 1;
+  int M = 0;                 // B*Hout*Wout
+  // B operand: weights [Npad][Ktot] bf16, k = (r*KW+s)*(C0+C1) + c
+  const bf16_t* wgt = nullptr;
+  int Ktot = 0, N = 0;
+  int ldw = 0;               // weight row stride in elements (0 = Ktot)
+  // batched GEMM (grid.z): element strides
+  int nbatch = 1;
+  int64_t a_bs = 0, w_bs = 0, o_bs = 0;
+  // epilogue: out = act(alpha*acc + bias[n] + rowvec[m/rows_per_vec][n]) + resid[m][n]
+  float alpha = 1.0f;
+  const float* bias = nullptr;
+  const float* rowvec = nullptr;
+  int rowvec_ld = 0, rows_per_vec = 1;
+  const bf16_t* resid = nullptr;
+  int resid_ld = 0;
+  int act = ACT_NONE;
+  void* out = nullptr;
+  int out_ld = 0;
+  int out_f32 = 0;
+  const bf16_t* zeros = nullptr;  // >= 256 B of zeros (masked rows / padding taps)
+  int tile = 0;                   // 0 = auto
+};
+void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p);
+const char* conv_gemm_last_config();
+
+// weight repack: fp32 [N][Cin][KH][KW] (torch conv / linear with KH=KW=1) -> bf16 [Npad][KH*KW*Cpad]
+// with zero padding; `geglu` interleaves value/gate rows in blocks of 32 (see conv_gemm.hip).
+void launch_repack_weight(hipStream_t st, const float* w, bf16_t* out, int N, int Cin, int KH,
+                          int KW, int Npad, int Cpad, int geglu, int64_t src_row_offset);
+
+// ---------------------------------------------------------------- normalisation / softmax (norm.hip)
+struct GroupNormParams {
+  const bf16_t* x = nullptr;   // NHWC bf16 [B][HW][C] (optionally a channel concat of two tensors)
+  const bf16_t* x1 = nullptr;
+  int C0 = 0, C1 = 0, ld0 = 0, ld1 = 0;
+  int B = 0, HW = 0, G = 32;
+  float eps = 1e-5f;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  // FiLM (use_scale_shift_norm, improved_ddpm/unet.py:253-257): y = gn(x)*(1+scale[b][c]) + shift[b][c]
+  const float* film = nullptr;  // [B][2*C]: scale | shift
+  int film_ld = 0;
+  int silu = 0;
+  bf16_t* y = nullptr;          // [B][HW][C] dense
+  float* partial = nullptr;     // workspace [B][S][G][2]
+  int S = 0;
+};
+int groupnorm_slabs(int B, int HW, int C);
+void launch_groupnorm(hipStream_t st, const GroupNormParams& p);
+
+void launch_layernorm(hipStream_t st, const bf16_t* x, int ldx, bf16_t* y, int ldy, int rows,
+                      int C, const float* gamma, const float* beta, float eps);
+// row softmax over fp32 scores [rows][cols] -> bf16 probabilities (VAE AttnBlock, model.py:193)
+void launch_softmax_rows(hipStream_t st, const float* s, int lds, bf16_t* p, int ldp, int64_t rows,
+                         int cols);
+
+// ---------------------------------------------------------------- attention (attn.hip)
+struct AttnParams {
+  const bf16_t* q = nullptr;   // [B][Tq][ldq], head h at column h*D
+  const bf16_t* k = nullptr;   // [B][Tk][ldk]
+  const bf16_t* vt = nullptr;  // V transposed: [B][H][Dv_pad][Tk_pad]  (keys contiguous)
+  bf16_t* o = nullptr;         // [B][Tq][ldo]
+  int B = 0, H = 0, Tq = 0, Tk = 0, D = 0;
+  int ldq = 0, ldk = 0, ldo = 0;
+  int64_t q_bs = 0, k_bs = 0, o_bs = 0;
+  int vt_dpad = 0, vt_tpad = 0;
+  float scale = 1.0f;
+  const float* obias = nullptr;  // [H*D] added to the output (value-projection bias: rows of P sum to 1)
+};
+void launch_attention(hipStream_t st, const AttnParams& p);
+// V [B][Tk][ldv] (head h at column h*D) -> Vt [B][H][Dpad][Tpad], zero padded
+void launch_transpose_v(hipStream_t st, const bf16_t* v, int ldv, int64_t v_bs, bf16_t* vt, int B,
+                        int H, int Tk, int D, int Dpad, int Tpad);
+
+// ---------------------------------------------------------------- elementwise (elementwise.hip)
+// fp32 NCHW [B][C][HW] -> bf16 NHWC [B][HW][Cpad] (pad channels zero), y = x*scale + shift
+void launch_nchw_to_nhwc(hipStream_t st, const float* x, bf16_t* y, int B, int C, int HW, int Cpad,
+                         float scale, float shift, int dup);
+// fp32/bf16 NHWC (ld) -> fp32 NCHW, y = x*scale + shift
+void launch_nhwc_to_nchw(hipStream_t st, const void* x, int x_f32, int ldx, float* y, int B, int C,
+                         int HW, float scale, float shift);
+// sinusoidal timestep embedding -> fp32 [B][dim]; mode 0: [cos|sin], freq = exp(-ln(1e4)*k/half)
+// (util.py:152-172); mode 1: [sin|cos], divisor half-1 (ddpm/diffusion.py:6-24)
+void launch_timestep_embedding(hipStream_t st, const StepCoef* tab, const int* step_ptr, int step,
+                               const float* t_explicit, float* out, int B, int dim, int mode);
+// small dense layer on fp32 vectors: y[b][n] = act_out(sum_k act_in(x[b][k])*W[n][k] + bias[n]); W bf16 or f32
+void launch_vec_linear(hipStream_t st, const float* x, int ldx, const float* W, const float* bias,
+                       float* y, int ldy, int B, int K, int N, int silu_in, int silu_out);
+// 2x2 average pool on NHWC bf16 (improved_ddpm Downsample without conv, unet.py:132-135)
+void launch_avgpool2(hipStream_t st, const bf16_t* x, bf16_t* y, int B, int H, int W, int C);
+// nearest x2 upsample (materialised; only where it cannot be folded into a conv)
+void launch_upsample2(hipStream_t st, const bf16_t* x, bf16_t* y, int B, int H, int W, int C);
+// DiagonalGaussianDistribution sample (distributions.py:24-37) from moments NHWC fp32 [B][HW][2*zc]:
+// z = (mean + exp(0.5*clamp(logvar,-30,20))*noise) * scale -> fp32 NCHW [B][zc][HW]
+void launch_posterior_sample(hipStream_t st, const float* mom, int ld, const float* noise,
+                             uint64_t seed, float* z, int B, int zc, int HW, float scale,
+                             int use_mean);
+void launch_fill_f32(hipStream_t st, float* p, float v, int64_t n);
+void launch_copy_strided_bf16(hipStream_t st, const bf16_t* src, int lds, bf16_t* dst, int ldd,
+                              int64_t rows, int cols);
+
+}  // namespace cd

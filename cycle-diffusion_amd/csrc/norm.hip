@@ -1,0 +1,263 @@
+// GroupNorm(32) (+SiLU, +FiLM), LayerNorm and row softmax for NHWC bf16 activations.
+//
+// Reference semantics:
+//   GroupNorm32 / Normalize: fp32 statistics, biased variance, eps 1e-5 (ResBlock,
+//     diffusionmodules/util.py:205-216) or 1e-6 (SpatialTransformer / VAE / Ho-DDPM,
+//     attention.py Normalize, model.py:38-39, ddpm/diffusion.py:32-33)
+//   SiLU written as x*sigmoid(x) (model.py:33-35); FiLM h = norm(h)*(1+scale)+shift
+//     (improved_ddpm/unet.py:253-257)
+//   nn.LayerNorm (attention.py:205-207), softmax over the last dim (model.py:193)
+// All three are HBM-bound: 16-byte vector accesses, fp32 math, deterministic reductions (no
+// atomics, so encode- and decode-time passes see bit-identical statistics for identical inputs).
+#include "common.h"
+#include "kernels.h"
+
+namespace cd {
+
+namespace {
+
+constexpr int GN_MAX_VPT = 4;  // supports C up to 8*256*4 = 8192
+
+__device__ inline const bf16_t* gn_src(const GroupNormParams& p, int b, int row, int c, int& off) {
+  if (c < p.C0) { off = c; return p.x + ((int64_t)b * p.HW + row) * p.ld0; }
+  off = c - p.C0;
+  return p.x1 + ((int64_t)b * p.HW + row) * p.ld1;
+}
+
+// grid (S, B). Each block reduces a slab of rows for all groups; thread owns a fixed set of 8-channel
+// vectors so per-channel sums stay in registers; fixed-order LDS reduction -> partial[b][s][g][2].
+__global__ __launch_bounds__(256) void k_gn_stats(GroupNormParams p, int rows_per_slab) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  const int C = p.C0 + p.C1;
+  const int nvec = C >> 3;
+  const int tid = threadIdx.x;
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int row_begin = s * rows_per_slab;
+  const int row_end = min(p.HW, row_begin + rows_per_slab);
+  int rif, vpt;
+  if (nvec <= 256) { rif = 256 / nvec; vpt = 1; }
+  else { rif = 1; vpt = (nvec + 255) >> 8; }
+  const int r0 = (nvec <= 256) ? tid / nvec : 0;
+  const int v0 = (nvec <= 256) ? tid % nvec : tid;
+  const bool active = (nvec <= 256) ? (tid < nvec * rif) : true;
+
+  float sum[GN_MAX_VPT][8], sq[GN_MAX_VPT][8];
+#pragma unroll
+  for (int j = 0; j < GN_MAX_VPT; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sum[j][e] = 0.f; sq[j][e] = 0.f; }
+
+  if (active) {
+    for (int row = row_begin + r0; row < row_end; row += rif) {
+#pragma unroll
+      for (int j = 0; j < GN_MAX_VPT; ++j) {
+        if (j < vpt) {
+          const int v = v0 + j * 256;
+          if (v < nvec) {
+            int off;
+            const bf16_t* base = gn_src(p, b, row, v * 8, off);
+            float f[8];
+            unpack8(*(const uint4*)(base + off), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sum[j][e] += f[e]; sq[j][e] += f[e] * f[e]; }
+          }
+        }
+      }
+    }
+  }
+  // LDS layout: sum[rif][C] then sq[rif][C]
+  float* lsum = sh;
+  float* lsq = sh + rif * C;
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < GN_MAX_VPT; ++j) {
+      if (j < vpt) {
+        const int v = v0 + j * 256;
+        if (v < nvec) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            lsum[r0 * C + v * 8 + e] = sum[j][e];
+            lsq[r0 * C + v * 8 + e] = sq[j][e];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < p.G) {
+    const int cpg = C / p.G;
+    float a = 0.f, q = 0.f;
+    for (int r = 0; r < rif; ++r)
+      for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += lsum[r * C + c]; q += lsq[r * C + c]; }
+    float* o = p.partial + (((int64_t)b * p.S + s) * p.G + tid) * 2;
+    o[0] = a; o[1] = q;
+  }
+}
+
+// grid (row_chunks, B): y = (x-mean)*rstd*gamma+beta [FiLM] [SiLU]
+__global__ __launch_bounds__(256) void k_gn_apply(GroupNormParams p, int rows_per_block) {
+  __shared__ float s_mean[64], s_rstd[64];
+  const int C = p.C0 + p.C1;
+  const int nvec = C >> 3;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int cpg = C / p.G;
+  if (tid < p.G) {
+    float a = 0.f, q = 0.f;
+    for (int s = 0; s < p.S; ++s) {
+      const float* o = p.partial + (((int64_t)b * p.S + s) * p.G + tid) * 2;
+      a += o[0]; q += o[1];
+    }
+    const float n = (float)cpg * (float)p.HW;
+    const float mean = a / n;
+    float var = q / n - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    s_mean[tid] = mean;
+    s_rstd[tid] = 1.0f / sqrtf(var + p.eps);
+  }
+  __syncthreads();
+  const int row_begin = blockIdx.x * rows_per_block;
+  const int row_end = min(p.HW, row_begin + rows_per_block);
+  const int total = (row_end - row_begin) * nvec;
+  for (int i = tid; i < total; i += 256) {
+    const int row = row_begin + i / nvec;
+    const int v = i % nvec;
+    const int c = v * 8;
+    int off;
+    const bf16_t* base = gn_src(p, b, row, c, off);
+    float f[8];
+    unpack8(*(const uint4*)(base + off), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (c + e) / cpg;
+      float y = (f[e] - s_mean[g]) * s_rstd[g];
+      y = y * p.gamma[c + e] + p.beta[c + e];
+      if (p.film) {
+        const float* fl = p.film + (int64_t)b * p.film_ld;
+        y = y * (1.0f + fl[c + e]) + fl[C + c + e];
+      }
+      if (p.silu) y = silu_f(y);
+      f[e] = y;
+    }
+    *(uint4*)(p.y + ((int64_t)b * p.HW + row) * C + c) = pack8(f);
+  }
+}
+
+// one wave per row; C multiple of 8, C <= 2048
+__global__ __launch_bounds__(256) void k_layernorm(const bf16_t* __restrict__ x, int ldx,
+                                                   bf16_t* __restrict__ y, int ldy, int rows, int C,
+                                                   const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nvec = C >> 3;
+  float f[4][8];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int v = lane + j * 64;
+    if (v < nvec) {
+      unpack8(*(const uint4*)(x + (int64_t)row * ldx + v * 8), f[j]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += f[j][e];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int v = lane + j * 64;
+    if (v < nvec) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = f[j][e] - mean; q += d * d; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int v = lane + j * 64;
+    if (v < nvec) {
+      float o8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        o8[e] = (f[j][e] - mean) * rstd * gamma[v * 8 + e] + beta[v * 8 + e];
+      *(uint4*)(y + (int64_t)row * ldy + v * 8) = pack8(o8);
+    }
+  }
+}
+
+// one block per row; three passes over an L2-resident fp32 row
+__global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ s, int lds_,
+                                                      bf16_t* __restrict__ p, int ldp, int cols) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const float* sr = s + row * lds_;
+  bf16_t* pr = p + row * ldp;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  float mx = -INFINITY;
+  for (int i = tid; i < cols; i += 256) mx = fmaxf(mx, sr[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if (lane == 0) red[w] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int i = tid; i < cols; i += 256) sum += __expf(sr[i] - mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if (lane == 0) red[w] = sum;
+  __syncthreads();
+  sum = (red[0] + red[1]) + (red[2] + red[3]);
+  const float inv = 1.0f / sum;
+  for (int i = tid; i < cols; i += 256) pr[i] = f2bf(__expf(sr[i] - mx) * inv);
+}
+
+}  // namespace
+
+int groupnorm_slabs(int B, int HW, int C) {
+  // enough blocks to cover the chip, at least 16 rows per slab
+  int want = ceil_div(1024, B > 0 ? B : 1);
+  int maxs = ceil_div(HW, 16);
+  int S = want < maxs ? want : maxs;
+  if (S < 1) S = 1;
+  if (S > 128) S = 128;
+  (void)C;
+  return S;
+}
+
+void launch_groupnorm(hipStream_t st, const GroupNormParams& p) {
+  const int C = p.C0 + p.C1;
+  CD_CHECK(C % 8 == 0 && C % p.G == 0 && p.G <= 64, "groupnorm: C=%d G=%d unsupported", C, p.G);
+  CD_CHECK(p.C0 % 8 == 0, "groupnorm: concat split must be a multiple of 8");
+  CD_CHECK((C >> 3) <= 256 * GN_MAX_VPT, "groupnorm: C too large");
+  CD_CHECK(p.partial && p.S > 0, "groupnorm: workspace missing");
+  const int nvec = C >> 3;
+  const int rif = nvec <= 256 ? 256 / nvec : 1;
+  const int rows_per_slab = ceil_div(p.HW, p.S);
+  const size_t lds = (size_t)rif * C * 2 * sizeof(float);
+  hipLaunchKernelGGL(k_gn_stats, dim3(p.S, p.B), dim3(256), lds, st, p, rows_per_slab);
+  int rows_per_block = 32768 / C;  // ~64 KB of bf16 per block
+  if (rows_per_block < 1) rows_per_block = 1;
+  hipLaunchKernelGGL(k_gn_apply, dim3(ceil_div(p.HW, rows_per_block), p.B), dim3(256), 0, st, p,
+                     rows_per_block);
+}
+
+void launch_layernorm(hipStream_t st, const bf16_t* x, int ldx, bf16_t* y, int ldy, int rows,
+                      int C, const float* gamma, const float* beta, float eps) {
+  CD_CHECK(C % 8 == 0 && C <= 2048, "layernorm: C=%d unsupported", C);
+  hipLaunchKernelGGL(k_layernorm, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, ldx, y, ldy, rows,
+                     C, gamma, beta, eps);
+}
+
+void launch_softmax_rows(hipStream_t st, const float* s, int lds_, bf16_t* p, int ldp, int64_t rows,
+                         int cols) {
+  hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)rows), dim3(256), 0, st, s, lds_, p, ldp, cols);
+}
+
+}  // namespace cd

@@ -1,0 +1,252 @@
+"""Host-side handle on the HIP engine: device memory and stream come from PyTorch-ROCm, every
+computation goes through the C ABI (include/cyclediff.h)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _ffi
+from ._ffi import NetDesc, check, ptr
+
+
+def make_desc(kind, *, image_size, in_channels, out_channels, model_channels, num_res_blocks, channel_mult,
+              attn=(), num_heads=-1, num_head_channels=-1, use_spatial_transformer=False, context_dim=0,
+              transformer_depth=1, use_scale_shift_norm=False, resblock_updown=False, conv_resample=True,
+              z_channels=0, embed_dim=0, double_z=False):
+    d = NetDesc()
+    d.kind = kind
+    d.image_size = image_size
+    d.in_channels, d.out_channels = in_channels, out_channels
+    d.model_channels, d.num_res_blocks = model_channels, num_res_blocks
+    d.n_mult = len(channel_mult)
+    for i, m in enumerate(channel_mult):
+        d.channel_mult[i] = int(m)
+    d.n_attn = len(attn)
+    for i, a in enumerate(attn):
+        d.attn[i] = int(a)
+    d.num_heads, d.num_head_channels = num_heads, num_head_channels
+    d.use_spatial_transformer = int(use_spatial_transformer)
+    d.context_dim = int(context_dim or 0)
+    d.transformer_depth = transformer_depth
+    d.use_scale_shift_norm = int(use_scale_shift_norm)
+    d.resblock_updown = int(resblock_updown)
+    d.conv_resample = int(conv_resample)
+    d.z_channels, d.embed_dim, d.double_z = z_channels, embed_dim, int(double_z)
+    return d
+
+
+# ---- the architectures the reference ships configs for ------------------------------------------
+def sd_v1_unet_desc(image_size=64):
+    """model/lib/stable_diffusion/configs/stable-diffusion/v1-inference.yaml:29-44"""
+    return make_desc(_ffi.CD_NET_UNET_OPENAI, image_size=image_size, in_channels=4, out_channels=4,
+                     model_channels=320, num_res_blocks=2, channel_mult=(1, 2, 4, 4), attn=(4, 2, 1),
+                     num_heads=8, use_spatial_transformer=True, context_dim=768)
+
+
+def ldm_text_unet_desc(image_size=32):
+    """model/lib/latentdiff/configs/latent-diffusion/txt2img-1p4B-eval.yaml (context 1280)"""
+    return make_desc(_ffi.CD_NET_UNET_OPENAI, image_size=image_size, in_channels=4, out_channels=4,
+                     model_channels=320, num_res_blocks=2, channel_mult=(1, 2, 4, 4), attn=(4, 2, 1),
+                     num_heads=8, use_spatial_transformer=True, context_dim=1280)
+
+
+def kl_f8_vae_desc():
+    """v1-inference.yaml:46-65 (first_stage_config ddconfig)"""
+    return make_desc(_ffi.CD_NET_VAE_KL, image_size=0, in_channels=3, out_channels=3, model_channels=128,
+                     num_res_blocks=2, channel_mult=(1, 2, 4, 4), z_channels=4, embed_dim=4, double_z=True)
+
+
+def afhq_iddpm_desc(image_size=256):
+    """improved_ddpm/script_util.py:5-22,45-104 (AFHQ_DICT; learn_sigma -> 6 output channels)"""
+    return make_desc(_ffi.CD_NET_UNET_OPENAI, image_size=image_size, in_channels=3, out_channels=6,
+                     model_channels=128, num_res_blocks=1, channel_mult=(1, 1, 2, 2, 4, 4),
+                     attn=(image_size // 16,), num_heads=4, num_head_channels=64,
+                     use_scale_shift_norm=True, resblock_updown=True)
+
+
+def ho_ddpm_desc(image_size, ch, ch_mult, num_res_blocks, attn_resolutions, in_channels=3, out_ch=3):
+    """ddpm/diffusion.py:192-205 (config.model.*)"""
+    return make_desc(_ffi.CD_NET_UNET_HO, image_size=image_size, in_channels=in_channels, out_channels=out_ch,
+                     model_channels=ch, num_res_blocks=num_res_blocks, channel_mult=tuple(ch_mult),
+                     attn=tuple(attn_resolutions))
+
+
+class Engine:
+    """One engine per rank / stream (cd_engine_create)."""
+
+    def __init__(self, device="cuda:0", workspace_bytes=None):
+        self.lib = _ffi.load_library()
+        if not torch.cuda.is_available():
+            raise _ffi.EngineError("no HIP device visible to PyTorch: the CycleDiffusion engine has no CPU fallback")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        if workspace_bytes is None:
+            free, _total = torch.cuda.mem_get_info(self.device)
+            workspace_bytes = int(min(96 << 30, free * 0.45))
+        self.stream = torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        check(self.lib.cd_engine_create(C.c_void_p(self.stream.cuda_stream), C.c_size_t(workspace_bytes), C.byref(h)))
+        self.h = h
+        self._descs = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            torch.cuda.synchronize(self.device)
+            self.lib.cd_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- networks
+    def create_net(self, desc):
+        nid = C.c_int(-1)
+        check(self.lib.cd_net_create(self.h, C.byref(desc), C.byref(nid)))
+        self._descs[nid.value] = desc
+        return nid.value
+
+    def net_params(self, net):
+        n = C.c_int()
+        check(self.lib.cd_net_param_count(self.h, net, C.byref(n)))
+        out = []
+        buf = C.create_string_buffer(512)
+        nd = C.c_int()
+        shp = (C.c_int64 * 4)()
+        for i in range(n.value):
+            check(self.lib.cd_net_param_info(self.h, net, i, buf, 512, C.byref(nd), shp))
+            out.append((buf.value.decode(), tuple(int(shp[j]) for j in range(nd.value))))
+        return out
+
+    def load_param(self, net, name, tensor):
+        t = tensor.detach().to(torch.float32).cpu().contiguous()
+        shp = (C.c_int64 * max(1, t.dim()))(*t.shape)
+        check(self.lib.cd_net_load_param(self.h, net, name.encode(), C.c_void_p(t.data_ptr()), t.dim(), shp))
+
+    def load_state_dict(self, net, sd, prefix="", strict=True):
+        """Load weights keyed by the reference's state_dict names (txt2img.py:25-42)."""
+        names = [n for n, _ in self.net_params(net)]
+        for n in names:
+            key = prefix + n
+            if key in sd:
+                self.load_param(net, n, sd[key])
+            elif strict:
+                raise KeyError("missing parameter %s" % key)
+        return self.missing(net)
+
+    def missing(self, net):
+        n = C.c_int()
+        buf = C.create_string_buffer(512)
+        check(self.lib.cd_net_missing_params(self.h, net, C.byref(n), buf, 512))
+        return n.value, buf.value.decode()
+
+    def random_init(self, net, seed=0, std=0.02):
+        """Synthetic weights for benchmarks: N(0, fan-in scaled) matrices, unit norms.
+        (There are no checkpoints in the tree)"""
+        g = torch.Generator().manual_seed(seed)
+        for name, shape in self.net_params(net):
+            if len(shape) == 1:
+                base = name.rsplit(".", 1)[0]
+                is_norm = name.endswith("weight") and (".norm" in name or "in_layers.0" in name or "out_layers.0" in name
+                                                       or name.startswith("out.0") or "norm_out" in name)
+                if is_norm:
+                    t = 1.0 + 0.05 * torch.randn(shape, generator=g)
+                else:
+                    t = 0.02 * torch.randn(shape, generator=g)
+                del base
+            else:
+                fan_in = int(np.prod(shape[1:]))
+                t = torch.randn(shape, generator=g) * (1.0 / np.sqrt(fan_in))
+            self.load_param(net, name, t)
+        n, first = self.missing(net)
+        assert n == 0, first
+
+    # ---- forward passes
+    def _f32(self, t):
+        assert t.is_cuda and t.dtype == torch.float32
+        return t.contiguous()
+
+    def unet_forward(self, net, x, t, ctx=None):
+        x, t = self._f32(x), self._f32(t.float())
+        ctx = self._f32(ctx) if ctx is not None else None
+        out_ch = self._out_channels(net)
+        y = torch.empty((x.shape[0], out_ch, x.shape[2], x.shape[3]), device=x.device, dtype=torch.float32)
+        check(self.lib.cd_unet_forward(self.h, net, ptr(x), ptr(t), ptr(ctx), x.shape[0],
+                                       ctx.shape[1] if ctx is not None else 0, ptr(y)))
+        return y
+
+    def _out_channels(self, net):
+        return self._descs[net].out_channels
+
+    def vae_encode(self, net, img, noise=None, seed=0, sample=True, scale=0.18215):
+        img = self._f32(img)
+        d = self._descs[net]
+        B, _, R, _ = img.shape
+        f = 2 ** (d.n_mult - 1)
+        z = torch.empty((B, d.embed_dim, R // f, R // f), device=img.device, dtype=torch.float32)
+        if noise is not None:
+            noise = self._f32(noise)
+        check(self.lib.cd_vae_encode(self.h, net, ptr(img), ptr(noise), C.c_uint64(seed), B, R, int(sample),
+                                     C.c_float(scale), ptr(z)))
+        return z
+
+    def vae_decode(self, net, z, scale=0.18215, out_mul=1.0, out_add=0.0):
+        z = self._f32(z)
+        d = self._descs[net]
+        B, _, hl, _ = z.shape
+        f = 2 ** (d.n_mult - 1)
+        img = torch.empty((B, d.out_channels, hl * f, hl * f), device=z.device, dtype=torch.float32)
+        check(self.lib.cd_vae_decode(self.h, net, ptr(z), B, hl, C.c_float(scale), C.c_float(out_mul),
+                                     C.c_float(out_add), ptr(img)))
+        return img
+
+    def dpm_encode(self, net, kind, x0, coef, ctx_c=None, ctx_uc=None, guidance=1.0, noise=None, seed=0,
+                   last_uses_x0=True):
+        """coef: numpy struct array (STEP_COEF_DTYPE) with K+1 rows; returns z [B, K+1, C, H, W]."""
+        x0 = self._f32(x0)
+        K = len(coef) - 1
+        B, Cc, H, W = x0.shape
+        z = torch.empty((B, K + 1, Cc, H, W), device=x0.device, dtype=torch.float32)
+        coef = np.ascontiguousarray(coef)
+        L = ctx_c.shape[1] if ctx_c is not None else (ctx_uc.shape[1] if ctx_uc is not None else 0)
+        check(self.lib.cd_dpm_encode(self.h, net, kind, ptr(x0),
+                                     ptr(self._f32(ctx_c)) if ctx_c is not None else None,
+                                     ptr(self._f32(ctx_uc)) if ctx_uc is not None else None,
+                                     L, C.c_float(guidance), B, K, C.c_void_p(coef.ctypes.data),
+                                     ptr(self._f32(noise)) if noise is not None else None,
+                                     C.c_uint64(seed), int(last_uses_x0), ptr(z)))
+        return z
+
+    def ddim_decode(self, net, kind, z, coef, n_eps=None, ctx_c=None, ctx_uc=None, guidance=1.0, noise_tail=None,
+                    seed=0):
+        """z [B, T, C, H, W]; coef K rows; returns x [B, C, H, W]."""
+        z = self._f32(z)
+        B, T, Cc, H, W = z.shape
+        K = len(coef)
+        if n_eps is None:
+            n_eps = T - 1
+        x = torch.empty((B, Cc, H, W), device=z.device, dtype=torch.float32)
+        coef = np.ascontiguousarray(coef)
+        L = ctx_c.shape[1] if ctx_c is not None else (ctx_uc.shape[1] if ctx_uc is not None else 0)
+        check(self.lib.cd_ddim_decode(self.h, net, kind, ptr(z), T, n_eps,
+                                      ptr(self._f32(ctx_c)) if ctx_c is not None else None,
+                                      ptr(self._f32(ctx_uc)) if ctx_uc is not None else None,
+                                      L, C.c_float(guidance), B, K, C.c_void_p(coef.ctypes.data),
+                                      ptr(self._f32(noise_tail)) if noise_tail is not None else None,
+                                      C.c_uint64(seed), ptr(x)))
+        return x
+
+    def pix_refine(self, net, kind, x, coef, noise=None, seed=0):
+        x = self._f32(x).clone()
+        R = len(coef) - 1
+        coef = np.ascontiguousarray(coef)
+        check(self.lib.cd_pix_refine(self.h, net, kind, ptr(x), x.shape[0], R, C.c_void_p(coef.ctypes.data),
+                                     ptr(self._f32(noise)) if noise is not None else None, C.c_uint64(seed)))
+        return x
+
+    def workspace_high_water(self):
+        v = C.c_size_t()
+        check(self.lib.cd_engine_workspace_high_water(self.h, C.byref(v)))
+        return v.value

@@ -1,0 +1,149 @@
+/* libcyclediff — C ABI of the MI355X-native CycleDiffusion engine.
+ *
+ * The reference (ChenWu98/cycle-diffusion) is pure Python/PyTorch and has no FFI; this header is
+ * the seam a maintainer binds (ctypes) underneath the reference's plugin API:
+ *   model/gan_wrapper/stable_diffusion_stochastic_text_wrapper.py:102-253  (SDStochasticTextWrapper)
+ *   model/gan_wrapper/latentdiff_stochastic_text_wrapper.py               (LatentDiffStochasticTextWrapper)
+ *   model/gan_wrapper/ddpm_ddim_wrapper.py:317-542                         (DDPMDDIMWrapper)
+ * Each entry point names the reference function it replaces.
+ *
+ * Conventions: every pointer is a DEVICE pointer unless its name ends in _host; tensors at the
+ * boundary are fp32, NCHW, contiguous (the reference's layout); all calls are asynchronous on the
+ * engine's HIP stream; return value 0 = ok, non-zero = error with text in cd_last_error();
+ * no exception crosses the ABI; one handle per rank / stream, not thread safe; the caller owns
+ * every buffer it passes, the engine owns weights and workspace.
+ */
+#ifndef CYCLEDIFF_H
+#define CYCLEDIFF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cd_engine* cd_handle;
+
+enum { CD_NET_UNET_OPENAI = 1, CD_NET_UNET_HO = 2, CD_NET_VAE_KL = 3 };
+enum { CD_SCHED_DDIM = 0, CD_SCHED_DDPM = 1 };
+
+/* Architecture descriptor (the hyper-parameters of the reference's YAML / dict configs):
+ *   UNET_OPENAI : ldm/modules/diffusionmodules/openaimodel.py:413-470 (SD v1, LDM text2img) and
+ *                 model/lib/ddpm_ddim/models/improved_ddpm/unet.py:401-470 (i_DDPM AFHQ)
+ *   UNET_HO     : model/lib/ddpm_ddim/models/ddpm/diffusion.py:192-290
+ *   VAE_KL      : ldm/models/autoencoder.py:285-333 + diffusionmodules/model.py:368-568 */
+typedef struct cd_net_desc {
+  int kind;
+  int image_size;          /* spatial size of the network input (latent 64, pixel 256, ...)      */
+  int in_channels, out_channels;
+  int model_channels;      /* `model_channels` / `ch`                                            */
+  int num_res_blocks;
+  int n_mult;  int channel_mult[8];
+  int n_attn;  int attn[8];/* OPENAI: downsample rates with attention; HO/VAE: resolutions       */
+  int num_heads;           /* -1 when num_head_channels is used                                   */
+  int num_head_channels;   /* -1 when num_heads is used                                           */
+  int use_spatial_transformer, context_dim, transformer_depth;
+  int use_scale_shift_norm, resblock_updown, conv_resample;
+  /* VAE */
+  int z_channels, embed_dim, double_z;
+  int reserved[8];
+} cd_net_desc;
+
+/* Per-step scheduler coefficients, evaluated by the host in fp32 in the reference's operation
+ * order (ddim.py:570-579 / ddpm_ddim_wrapper.py:291-302); see csrc/kernels.h StepCoef. */
+typedef struct cd_step_coef {
+  float sa, s1a, sap, dirc, sigma, r, t_mask;
+  int32_t t;
+} cd_step_coef;
+
+const char* cd_last_error(void);
+int cd_version(void);
+
+/* engine lifetime; `hip_stream` is a hipStream_t (0 = default stream) */
+int cd_engine_create(void* hip_stream, size_t workspace_bytes, cd_handle* out);
+int cd_engine_destroy(cd_handle h);
+int cd_engine_workspace_high_water(cd_handle h, size_t* bytes);
+
+/* networks: build from a descriptor, then load weights by the reference's state_dict names
+ * (replaces load_model_from_config, model/lib/stable_diffusion/txt2img.py:25-42, and
+ *  generator.load_state_dict, ddpm_ddim_wrapper.py:378-379) */
+int cd_net_create(cd_handle h, const cd_net_desc* desc, int* net_id);
+int cd_net_param_count(cd_handle h, int net, int* n);
+int cd_net_param_info(cd_handle h, int net, int index, char* name, int name_cap, int* ndim, int64_t shape[4]);
+int cd_net_load_param(cd_handle h, int net, const char* name, const float* data_host, int ndim,
+                      const int64_t* shape);
+int cd_net_missing_params(cd_handle h, int net, int* n_missing, char* first_name, int name_cap);
+
+/* eps_hat = UNet(x, t, context)  — LatentDiffusion.apply_model -> DiffusionWrapper.forward ->
+ * UNetModel.forward (ddpm.py:882-983,1392-1394; openaimodel.py:710-742) and DDPM.forward
+ * (ddpm/diffusion.py:292-337). x [B,C,H,W]; t [B] float timesteps; ctx [B,L,Dc] or NULL;
+ * eps_out [B,Cout,H,W]. */
+int cd_unet_forward(cd_handle h, int net, const float* x, const float* t, const float* ctx, int B,
+                    int ctx_len, float* eps_out);
+
+/* z0 = scale * posterior(E(img)).sample() (or .mode() when sample==0) — encode_first_stage +
+ * get_first_stage_encoding (ddpm.py:817-854, 536-543); img [B,3,R,R] in [-1,1]; noise [B,zc,R/8,R/8]
+ * or NULL (then Philox(seed)); z0 [B,zc,R/8,R/8]. */
+int cd_vae_encode(cd_handle h, int net, const float* img, const float* noise, uint64_t seed, int B, int R,
+                  int sample, float scale, float* z0);
+/* img = D(z0/scale)*out_mul + out_add — decode_first_stage (ddpm.py:698-755); the wrapper's
+ * post_process (x+1)/2 (sd_wrapper:135-137) is out_mul=0.5, out_add=0.5. */
+int cd_vae_decode(cd_handle h, int net, const float* z0, int B, int hlat, float scale, float out_mul,
+                  float out_add, float* img);
+
+/* DPM-Encoder: DDIMSampler.ddpm_ddim_encoding / _ddpm_ddim_encoding (ddim.py:230-286, 450-501)
+ * and DDPMDDIMWrapper.encode's loop (ddpm_ddim_wrapper.py:483-520).
+ *   x0 [B,C,H,W]; ctx_c / ctx_uc [B,L,Dc] or NULL (pixel DDPMs); guidance g as in ddim.py:550-559;
+ *   coef_host: K+1 rows — row K initialises x_T (sa, s1a), rows K-1..0 are the loop steps;
+ *   noise [K,B,C,H,W] (slot 0 = x_T draw, slots 1..K-1 = per-step draws in loop order) or NULL;
+ *   z_out [B,K+1,C,H,W] = stack([x_T, eps_{K-1}, ..., eps_0], dim=1) (sd_wrapper:203).
+ *   last_uses_x0: 1 = latent sampler (index 0 returns x0, no draw, ddim.py:583-584);
+ *                 0 = pixel wrapper (K-1 ordinary steps; z has K entries). */
+int cd_dpm_encode(cd_handle h, int net, int sched_kind, const float* x0, const float* ctx_c,
+                  const float* ctx_uc, int ctx_len, float guidance, int B, int K,
+                  const cd_step_coef* coef_host, const float* noise, uint64_t seed,
+                  int last_uses_x0, float* z_out);
+
+/* Decode with injected eps: DDIMSampler.sample_with_eps / ddim_sampling_with_eps /
+ * p_sample_ddim_with_eps (ddim.py:170-228, 395-448, 603-646) and DDPMDDIMWrapper.generate
+ * (ddpm_ddim_wrapper.py:392-455).
+ *   z [B,T,C,H,W] with z[:,0] = x_T and z[:,1+i] the eps of loop step i; steps i >= n_eps draw fresh
+ *   noise (`noise_tail` [K-n_eps,B,C,H,W] or Philox). coef_host: K rows in loop order index K-1..0
+ *   stored at row index = k. x_out [B,C,H,W]. */
+int cd_ddim_decode(cd_handle h, int net, int sched_kind, const float* z, int z_slots, int n_eps,
+                   const float* ctx_c, const float* ctx_uc, int ctx_len, float guidance, int B, int K,
+                   const cd_step_coef* coef_host, const float* noise_tail, uint64_t seed, float* x_out);
+
+/* Stochastic refinement (ddpm_ddim_wrapper.py:431-453): x_t = sa*x + s1a*n (row R of coef_host),
+ * then R random-noise steps rows R-1..0. noise [R+1,B,C,H,W] or NULL. In/out x [B,C,H,W]. */
+int cd_pix_refine(cd_handle h, int net, int sched_kind, float* x, int B, int R,
+                  const cd_step_coef* coef_host, const float* noise, uint64_t seed);
+
+/* ---- single-kernel entry points (parity tests call the HIP kernels through these) ----------- */
+int cd_op_pack_conv_weight(cd_handle h, const float* w_host, int N, int Cin, int KH, int KW, int geglu,
+                           void** packed_dev, int* Npad, int* Cpad);
+int cd_op_free(cd_handle h, void* dev);
+/* x: fp32 NCHW [B,C0(,+C1),H,W] (x1 optional second source); y: fp32 NCHW [B,N,Ho,Wo] */
+int cd_op_conv2d(cd_handle h, const float* x0, int C0, const float* x1, int C1, int B, int H, int W,
+                 const void* packed_w, int N, int KH, int KW, int stride, int pad, int asym_pad, int up,
+                 const float* bias, const float* rowvec, const float* resid, int act, int tile, float* y);
+int cd_op_groupnorm(cd_handle h, const float* x, int B, int C, int H, int W, int G, float eps,
+                    const float* gamma, const float* beta, const float* film, int silu, float* y);
+int cd_op_layernorm(cd_handle h, const float* x, int rows, int C, const float* gamma, const float* beta,
+                    float eps, float* y);
+/* q [B,Tq,H*D], k,v [B,Tk,H*D] fp32 -> o [B,Tq,H*D] */
+int cd_op_attention(cd_handle h, const float* q, const float* k, const float* v, int B, int H, int Tq,
+                    int Tk, int D, float scale, int use_transpose_kernel, float* o);
+int cd_op_softmax_rows(cd_handle h, const float* s, int64_t rows, int cols, float* p);
+int cd_op_timestep_embedding(cd_handle h, const float* t, int B, int dim, int mode, float* out);
+/* one scheduler step on explicit tensors (bit-exact checks): mode 0 init_xt, 1 encode, 2 decode */
+int cd_op_sched_step(cd_handle h, int mode, int sched_kind, const cd_step_coef* coef_host, const float* x0,
+                     float* xt, const float* eps_hat, int cfg, float guidance, const float* noise,
+                     const float* eps_in, int is_last, int B, int C, int HW, float* z_slot);
+/* raw MFMA / LDS layout probe used by tests/test_gpu_probe.py */
+int cd_op_probe(cd_handle h, int which, const void* in, void* out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CYCLEDIFF_H */
