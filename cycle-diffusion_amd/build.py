@@ -46,7 +46,8 @@ def build(force=False, verbose=False):
         obj = os.path.join(OBJDIR, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            extra = ["-ffp-contract=off"] if s == "sched.hip" else []  # scheduler math: reference op order, no FMA
+            jobs.append([hipcc] + FLAGS + extra + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

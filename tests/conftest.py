@@ -1,0 +1,68 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no HIP device in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def engine():
+    import cycle_diffusion_amd as cda
+    eng = cda.Engine("cuda:0")
+    yield eng
+    eng.close()
+
+
+class _Report:
+    """Collects numeric parity figures; dumped to gpurun_out/parity_report.json at session end."""
+
+    def __init__(self):
+        self.rows = []
+
+    def add(self, name, **kw):
+        self.rows.append(dict(name=name, **kw))
+
+
+_REPORT = _Report()
+
+
+@pytest.fixture(scope="session")
+def report():
+    return _REPORT
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _REPORT.rows:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report.json"), "w") as f:
+            json.dump(_REPORT.rows, f, indent=1)
+    except OSError:
+        pass

@@ -1,0 +1,247 @@
+"""Per-kernel parity: every HIP kernel (called through the C ABI) against a plain PyTorch fp32
+reference of the same op on identical, bf16-representable inputs.
+
+Tolerances: the kernels keep bf16 operands / fp32 accumulation and round outputs to bf16 once, so
+max-abs error is bounded by ~2^-8 of the output scale (REL_TOL) and the mean error by MEAN_TOL.
+Scheduler kernels are fp32 with the reference's operation order and must be bit-exact.
+"""
+import math
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import _ops
+from _ops import bf16_round as r16
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 2.0e-2   # max |err| / max |ref|
+MEAN_TOL = 6.0e-3  # mean |err| / mean |ref|
+
+
+def _check(report, name, got, ref, rel=REL_TOL, mean=MEAN_TOL):
+    st = _ops.err_stats(got, ref)
+    report.add(name, **st)
+    assert st["finite"], name
+    assert st["rel_to_max"] < rel, (name, st)
+    assert st["mean_rel"] < mean, (name, st)
+
+
+def test_probe_mfma_layout(engine, report):
+    out = _ops.probe(engine, 0, 3072).reshape(3, 64, 16)
+    lane = np.arange(64)[:, None]
+    reg = np.arange(16)[None, :]
+    rows = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    cols = np.broadcast_to(lane & 31, (64, 16))
+    report.add("probe_mfma", rowmap_ok=bool((out[0] == rows + 1).all()), colmap_ok=bool((out[1] == cols + 1).all()),
+               ksum=float(out[2].mean()))
+    assert (out[0] == rows + 1).all(), out[0][:4]
+    assert (out[1] == cols + 1).all(), out[1][:4]
+    assert (out[2] == 136.0).all()
+
+
+def test_probe_tr_read(engine, report):
+    # informational: records the ds_read_b64_tr_b16 lane->element map for the attention V^T path
+    out = _ops.probe(engine, 1, 256).reshape(64, 4)
+    report.add("probe_tr_b16", lanes0_3=out[:4].tolist(), lane16=out[16].tolist(), lane63=out[63].tolist())
+    assert np.isfinite(out).all()
+
+
+CONV_CASES = [
+    # name, B, C0, C1, H, W, N, k, stride, pad, asym, up, bias, rowvec, resid, act, tile
+    ("3x3_64_64_16", 2, 64, 0, 16, 16, 64, 3, 1, 1, False, False, True, False, False, 0, 0),
+    ("3x3_320_320_16_t1", 2, 320, 0, 16, 16, 320, 3, 1, 1, False, False, True, True, True, 0, 1),
+    ("3x3_320_320_16_t2", 2, 320, 0, 16, 16, 320, 3, 1, 1, False, False, True, True, True, 0, 2),
+    ("3x3_320_320_16_t3", 2, 320, 0, 16, 16, 320, 3, 1, 1, False, False, True, True, True, 0, 3),
+    ("3x3_stride2_pad1", 2, 128, 0, 16, 16, 128, 3, 2, 1, False, False, True, False, False, 0, 0),
+    ("3x3_stride2_asym", 2, 128, 0, 16, 16, 128, 3, 2, 0, True, False, True, False, False, 0, 0),
+    ("3x3_upsample", 2, 128, 0, 8, 8, 128, 3, 1, 1, False, True, True, False, False, 0, 0),
+    ("3x3_concat_k64", 2, 128, 64, 16, 16, 192, 3, 1, 1, False, False, True, False, False, 0, 0),
+    ("3x3_concat_k32", 2, 64, 32, 16, 16, 96, 3, 1, 1, False, False, True, False, False, 0, 0),
+    ("1x1_concat_skip", 2, 128, 64, 16, 16, 64, 1, 1, 0, False, False, True, False, False, 0, 0),
+    ("1x1_silu", 1, 256, 0, 12, 12, 256, 1, 1, 0, False, False, True, False, False, 1, 0),
+    ("1x1_gelu", 1, 64, 0, 8, 8, 96, 1, 1, 0, False, False, True, False, False, 2, 0),
+    ("3x3_cin4_pad32", 2, 4, 0, 16, 16, 64, 3, 1, 1, False, False, True, False, False, 0, 0),
+    ("3x3_cout4", 2, 64, 0, 16, 16, 4, 3, 1, 1, False, False, True, False, False, 0, 0),
+    ("3x3_cout3_cin128", 1, 128, 0, 24, 24, 3, 3, 1, 1, False, False, True, False, False, 0, 0),
+    ("3x3_ragged_M", 1, 64, 0, 10, 10, 64, 3, 1, 1, False, False, True, False, True, 0, 0),
+    ("3x3_1280_8x8", 2, 1280, 0, 8, 8, 1280, 3, 1, 1, False, False, True, True, True, 0, 0),
+    ("3x3_2560_1280_skip", 1, 1280, 1280, 8, 8, 1280, 3, 1, 1, False, False, True, False, False, 0, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d(engine, report, case):
+    name, B, C0, C1, H, W, N, k, stride, pad, asym, up, has_bias, has_rv, has_res, act, tile = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % (2 ** 31))
+    x0 = r16(torch.randn(B, C0, H, W, generator=g))
+    x1 = r16(torch.randn(B, C1, H, W, generator=g)) if C1 else None
+    Cin = C0 + C1
+    w = r16(torch.randn(N, Cin, k, k, generator=g) / math.sqrt(Cin * k * k))
+    bias = torch.randn(N, generator=g) * 0.5 if has_bias else None
+    x = torch.cat([x0, x1], 1) if C1 else x0
+    if up:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    if asym:
+        x = F.pad(x, (0, 1, 0, 1))
+    ref = F.conv2d(x, w, bias, stride=stride, padding=0 if asym else pad)
+    rv = torch.randn(B, N, generator=g) if has_rv else None
+    if rv is not None:
+        ref = ref + rv[:, :, None, None]
+    if act == 1:
+        ref = F.silu(ref)
+    elif act == 2:
+        ref = F.gelu(ref)
+    res = r16(torch.randn(ref.shape, generator=g)) if has_res else None
+    if res is not None:
+        ref = ref + res
+    got = _ops.conv2d(engine, x0, w, x1=x1, stride=stride, pad=pad, asym=asym, up=up, bias=bias, rowvec=rv,
+                      resid=res, act=act, tile=tile)
+    # the op wrapper returns the fp32 epilogue result (out_f32 path): only operand rounding remains
+    _check(report, "conv2d/" + name, got, ref, rel=5e-3, mean=2e-3)
+
+
+def test_conv_geglu(engine, report):
+    g = torch.Generator().manual_seed(7)
+    M, K, N = 512, 320, 2560  # GEGLU.proj: dim -> 2*inner (attention.py:37-44)
+    x = r16(torch.randn(1, K, M, 1, generator=g))
+    w = r16(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g) * 0.3
+    h = F.linear(x[0, :, :, 0].t(), w, b)
+    val, gate = h.chunk(2, dim=-1)
+    ref = (val * F.gelu(gate)).t()[None, :, :, None]
+    for tile in (1, 2):
+        got = _ops.conv2d(engine, x, w, pad=0, bias=b, geglu=True, tile=tile)
+        _check(report, "conv2d/geglu_t%d" % tile, got, ref, rel=5e-3, mean=3e-3)
+
+
+GN_CASES = [("c320", 2, 320, 16, 16, 1e-5, True, False), ("c64", 2, 64, 8, 8, 1e-6, False, False),
+            ("c2560", 1, 2560, 8, 8, 1e-5, True, False), ("c128_film", 2, 128, 16, 16, 1e-5, True, True),
+            ("c32", 1, 32, 32, 32, 1e-6, True, False), ("c1920", 1, 1920, 16, 16, 1e-5, True, False),
+            ("c128_big", 1, 128, 96, 96, 1e-6, True, False)]
+
+
+@pytest.mark.parametrize("case", GN_CASES, ids=[c[0] for c in GN_CASES])
+def test_groupnorm(engine, report, case):
+    name, B, C, H, W, eps, silu, film = case
+    g = torch.Generator().manual_seed(11)
+    x = r16(torch.randn(B, C, H, W, generator=g) * 2.0 + 0.5)
+    gamma = 1.0 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    ref = F.group_norm(x, 32, gamma, beta, eps)
+    fl = None
+    if film:
+        fl = 0.3 * torch.randn(B, 2 * C, generator=g)
+        scale, shift = fl.chunk(2, dim=1)
+        ref = ref * (1 + scale[:, :, None, None]) + shift[:, :, None, None]
+    if silu:
+        ref = F.silu(ref)
+    got = _ops.groupnorm(engine, x, gamma, beta, eps, silu=silu, film=fl)
+    _check(report, "groupnorm/" + name, got, ref, rel=1.5e-2, mean=4e-3)
+
+
+@pytest.mark.parametrize("C", [320, 640, 1280, 64])
+def test_layernorm(engine, report, C):
+    g = torch.Generator().manual_seed(13)
+    x = r16(torch.randn(300, C, generator=g) * 1.5 + 0.3)
+    gamma = 1.0 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    ref = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    got = _ops.layernorm(engine, x, gamma, beta)
+    _check(report, "layernorm/c%d" % C, got, ref, rel=1.5e-2, mean=4e-3)
+
+
+ATTN_CASES = [("d40_self", 2, 8, 256, 256, 40), ("d80_self", 1, 8, 256, 256, 80), ("d160_self", 1, 8, 64, 64, 160),
+              ("d40_cross77", 2, 8, 256, 77, 40), ("d160_cross77", 1, 8, 64, 77, 160), ("d64_iddpm", 1, 4, 256, 256, 64),
+              ("d32_1head", 1, 1, 64, 64, 32), ("d128_1head", 1, 1, 320, 320, 128), ("d40_long", 1, 2, 1024, 1024, 40)]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
+def test_attention(engine, report, case):
+    name, B, H, Tq, Tk, D = case
+    g = torch.Generator().manual_seed(17)
+    C = H * D
+    q = r16(torch.randn(B, Tq, C, generator=g))
+    k = r16(torch.randn(B, Tk, C, generator=g))
+    v = r16(torch.randn(B, Tk, C, generator=g))
+    scale = D ** -0.5
+    qh = q.view(B, Tq, H, D).transpose(1, 2)
+    kh = k.view(B, Tk, H, D).transpose(1, 2)
+    vh = v.view(B, Tk, H, D).transpose(1, 2)
+    att = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1)
+    ref = (att @ vh).transpose(1, 2).reshape(B, Tq, C)
+    got = _ops.attention(engine, q, k, v, H, scale)
+    _check(report, "attention/" + name, got, ref, rel=2e-2, mean=1e-2)
+
+
+def test_softmax_rows(engine, report):
+    g = torch.Generator().manual_seed(19)
+    s = torch.randn(70, 1000, generator=g) * 4
+    got = _ops.softmax_rows(engine, s)
+    _check(report, "softmax_rows", got, torch.softmax(s, -1), rel=1e-2, mean=5e-3)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_timestep_embedding(engine, report, mode):
+    t = torch.tensor([1.0, 11.0, 501.0, 981.0, 999.0])
+    dim = 320 if mode == 0 else 128
+    half = dim // 2
+    if mode == 0:  # util.py:152-172
+        freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+        a = t[:, None] * freqs[None]
+        ref = torch.cat([torch.cos(a), torch.sin(a)], -1)
+    else:  # ddpm/diffusion.py:6-24
+        e = math.log(10000) / (half - 1)
+        f = torch.exp(torch.arange(half, dtype=torch.float32) * -e)
+        a = t[:, None] * f[None]
+        ref = torch.cat([torch.sin(a), torch.cos(a)], 1)
+    got = _ops.timestep_embedding(engine, t, dim, mode)
+    st = _ops.err_stats(got, ref)
+    report.add("timestep_embedding/mode%d" % mode, **st)
+    assert st["max_abs"] < 2e-4, st  # device sin/cos of arguments up to ~1e3
+
+
+def _coef(a_t, a_prev, sigma):
+    f = np.float32
+    a_t, a_prev, sigma = f(a_t), f(a_prev), f(sigma)
+    return (np.sqrt(a_t), np.sqrt(f(1) - a_t), np.sqrt(a_prev), np.sqrt(f(1) - a_prev - sigma * sigma), sigma,
+            np.sqrt(f(1) - a_t), f(1), 0)
+
+
+def test_sched_steps_bit_exact(engine, report):
+    """fp32 scheduler kernels vs the reference's tensor expressions (ddim.py:576-600, 634-645)."""
+    g = torch.Generator().manual_seed(23)
+    B, C, H, W = 2, 4, 16, 16
+    x0, xt, e_u, e_c, nz, eps = [torch.randn(B, C, H, W, generator=g) for _ in range(6)]
+    a_t, a_prev, sig = 0.4321, 0.4876, 0.0123
+    co = _coef(a_t, a_prev, sig)
+    at = torch.full((B, 1, 1, 1), float(np.float32(a_t)))
+    ap = torch.full((B, 1, 1, 1), float(np.float32(a_prev)))
+    sg = torch.full((B, 1, 1, 1), float(np.float32(sig)))
+    s1 = torch.full((B, 1, 1, 1), float(np.sqrt(np.float32(1) - np.float32(a_t))))
+    # init x_T
+    ref_xT = at.sqrt() * x0 + (1 - at).sqrt() * nz
+    got_xT, _ = _ops.sched_step(engine, 0, 0, co, x0=x0, noise=nz)
+    assert torch.equal(got_xT, ref_xT)
+    # encode step without / with CFG
+    for cfg, gs in ((False, 1.0), (True, 3.0)):
+        e_t = e_u + gs * (e_c - e_u) if cfg else e_c
+        et_post = (xt - at.sqrt() * x0) / (1 - at).sqrt()
+        x_next = ap.sqrt() * x0 + (1. - ap - sg ** 2).sqrt() * et_post + sg * nz
+        pred_x0 = (xt - s1 * e_t) / at.sqrt()
+        ref_eps = (x_next - ap.sqrt() * pred_x0 - (1. - ap - sg ** 2).sqrt() * e_t) / sg / 1.0
+        eh = torch.cat([e_u, e_c], 0) if cfg else e_c
+        got_xn, got_eps = _ops.sched_step(engine, 1, 0, co, x0=x0, xt=xt, eps_hat=eh, cfg=cfg, g=gs, noise=nz)
+        assert torch.equal(got_xn, x_next), (got_xn - x_next).abs().max()
+        assert torch.equal(got_eps, ref_eps), (got_eps - ref_eps).abs().max()
+        # decode step with injected eps
+        x_prev = ap.sqrt() * pred_x0 + (1. - ap - sg ** 2).sqrt() * e_t + sg * eps * 1.0
+        got_xp, _ = _ops.sched_step(engine, 2, 0, co, xt=xt, eps_hat=eh, cfg=cfg, g=gs, eps_in=eps)
+        assert torch.equal(got_xp, x_prev), (got_xp - x_prev).abs().max()
+    # last encode step returns x0 without a draw
+    got_xn, _ = _ops.sched_step(engine, 1, 0, co, x0=x0, xt=xt, eps_hat=e_c, noise=None, is_last=True)
+    assert torch.equal(got_xn, x0)
+    report.add("sched_steps_bit_exact", ok=True)
