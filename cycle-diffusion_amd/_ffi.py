@@ -46,9 +46,12 @@ _VP, _I, _F, _U64, _SZ, _I64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_s
 SIGNATURES = {
     "cd_last_error": [],
     "cd_version": [],
+    "cd_act_format": [],
     "cd_engine_create": [_VP, _SZ, C.POINTER(_VP)],
     "cd_engine_destroy": [_VP],
     "cd_engine_workspace_high_water": [_VP, C.POINTER(_SZ)],
+    "cd_prof_enable": [_VP, _I],
+    "cd_prof_collect": [_VP, C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "cd_net_create": [_VP, C.POINTER(NetDesc), C.POINTER(_I)],
     "cd_net_param_count": [_VP, _I, C.POINTER(_I)],
     "cd_net_param_info": [_VP, _I, _I, C.c_char_p, _I, C.POINTER(_I), C.POINTER(_I64)],

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_attention(AttnParams p) {
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         const bf16x8 kf = *(const bf16x8*)(Ks + (kh * 32 + qi) * KLD + ks * 16 + 8 * half);
-        s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kh], 0, 0, 0);
+        s[kh] = CD_MFMA_32x32x16(kf, qf[ks], s[kh]);
       }
     }
     // ---- scale, mask keys beyond Tk, running max
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_attention(AttnParams p) {
           bf16x8 vf;
           vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
           vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+          o[dt] = CD_MFMA_32x32x16(vf, pf, o[dt]);
         }
       }
   }

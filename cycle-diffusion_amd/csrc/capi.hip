@@ -17,6 +17,7 @@ struct cd_engine {
   std::vector<std::unique_ptr<Net>> nets;
   std::vector<ParamStore*> op_stores;  // storage behind cd_op_pack_conv
   ParamStore op_params;
+  std::unique_ptr<KernelProfiler> prof;
   Ctx ctx() {
     Ctx c; c.st = st; c.arena = &arena; c.zeros = zeros; c.gn_partial = gn_partial;
     c.gn_partial_floats = gn_partial_floats;
@@ -56,6 +57,7 @@ extern "C" {
 
 const char* cd_last_error(void) { return g_err.c_str(); }
 int cd_version(void) { return 100; }
+int cd_act_format(void) { return CD_ACT_FP16 ? 1 : 0; }
 
 int cd_engine_create(void* hip_stream, size_t workspace_bytes, cd_handle* out) {
   CD_API_BEGIN
@@ -80,10 +82,28 @@ int cd_engine_destroy(cd_handle h) {
   CD_API_BEGIN
   if (h) {
     (void)hipStreamSynchronize(h->st);
+    if (g_conv_prof == h->prof.get()) g_conv_prof = nullptr;
     if (h->zeros) (void)hipFree(h->zeros);
     if (h->gn_partial) (void)hipFree(h->gn_partial);
     delete h;
   }
+  CD_API_END
+}
+
+int cd_prof_enable(cd_handle h, int on) {
+  CD_API_BEGIN
+  CD_CHECK(h, "null handle");
+  if (!h->prof) h->prof.reset(new KernelProfiler());
+  h->prof->enabled = on != 0;
+  g_conv_prof = on ? h->prof.get() : nullptr;
+  CD_API_END
+}
+
+int cd_prof_collect(cd_handle h, int* launches, double* total_ms, double* total_flops) {
+  CD_API_BEGIN
+  CD_CHECK(h && h->prof && launches && total_ms && total_flops, "profiler not enabled");
+  HIP_CHECK(hipStreamSynchronize(h->st));
+  h->prof->collect(launches, total_ms, total_flops);
   CD_API_END
 }
 
@@ -527,16 +547,16 @@ __global__ void k_probe_mfma(float* out) {
   f32x16 acc;
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   if (lane < 32) { a[0] = (short)f2bf((float)(lane + 1)); b[0] = (short)f2bf(1.0f); }
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  acc = CD_MFMA_32x32x16(a, b, acc);
   for (int r = 0; r < 16; ++r) out[lane * 16 + r] = acc[r];
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   if (lane < 32) { a[0] = (short)f2bf(1.0f); b[0] = (short)f2bf((float)(lane + 1)); }
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  acc = CD_MFMA_32x32x16(a, b, acc);
   for (int r = 0; r < 16; ++r) out[1024 + lane * 16 + r] = acc[r];
   // k-slot check: A[i][k] = 1 for all i, only k = kk set; B[kk][j] = kk+1 -> D = sum over matching k
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   for (int j = 0; j < 8; ++j) { a[j] = (short)f2bf(1.0f); b[j] = (short)f2bf((float)(8 * (lane >> 5) + j + 1)); }
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  acc = CD_MFMA_32x32x16(a, b, acc);
   for (int r = 0; r < 16; ++r) out[2048 + lane * 16 + r] = acc[r];  // expect 1+2+...+16 = 136
 }
 __global__ void k_probe_tr(float* out) {

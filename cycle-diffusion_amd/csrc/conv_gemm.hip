@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = CD_MFMA_32x32x16(af[i], bfr[j], acc[i][j]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -309,6 +309,31 @@ thread_local const char* g_last_cfg = "";
 
 const char* conv_gemm_last_config() { return g_last_cfg; }
 
+KernelProfiler* g_conv_prof = nullptr;
+
+void KernelProfiler::next_pair(hipEvent_t* a, hipEvent_t* b, double fl) {
+  if (used + 2 > (int)events.size()) {
+    const size_t old = events.size();
+    events.resize(old + 1024);
+    for (size_t i = old; i < events.size(); ++i) HIP_CHECK(hipEventCreate(&events[i]));
+  }
+  *a = events[used]; *b = events[used + 1];
+  used += 2;
+  flops.push_back(fl);
+}
+void KernelProfiler::collect(int* launches, double* total_ms, double* total_flops) {
+  double ms = 0, fl = 0;
+  for (int i = 0; i + 1 < used; i += 2) {
+    HIP_CHECK(hipEventSynchronize(events[i + 1]));
+    float t = 0;
+    HIP_CHECK(hipEventElapsedTime(&t, events[i], events[i + 1]));
+    ms += t; fl += flops[i / 2];
+  }
+  *launches = used / 2; *total_ms = ms; *total_flops = fl;
+  used = 0; flops.clear();
+}
+KernelProfiler::~KernelProfiler() { for (auto e : events) (void)hipEventDestroy(e); }
+
 void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   const int Ctot = p.C0 + p.C1;
   CD_CHECK(p.C0 % 32 == 0 && p.C1 % 32 == 0, "conv_gemm: channels must be multiples of 32 (C0=%d C1=%d)", p.C0, p.C1);
@@ -331,6 +356,16 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
     else tile = 3;
   }
   if (p.act == ACT_GEGLU && tile == 3) tile = 2;
+  KernelProfiler* prof = g_conv_prof;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (prof && prof->enabled) {
+    prof->next_pair(&e0, &e1, 2.0 * (double)p.M * (double)p.N * (double)p.Ktot * (double)p.nbatch);
+    (void)hipEventRecord(e0, st);
+  }
+  struct Closer {  // record the stop event on every exit path of the switch below
+    hipEvent_t e; hipStream_t s;
+    ~Closer() { if (e) (void)hipEventRecord(e, s); }
+  } closer{e1, st};
   if (k64) {
     switch (tile) {
       case 1: g_last_cfg = "128x128x64"; launch_cfg<128, 128, 64, 2, 2>(st, p); break;

@@ -1,5 +1,7 @@
 // Launcher declarations for the hand-written gfx950 kernels (implementation: *.hip in this dir).
 #pragma once
+#include <vector>
+
 #include "common.h"
 
 namespace cd {
@@ -75,6 +77,20 @@ struct ConvGemmParams {
 };
 void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p);
 const char* conv_gemm_last_config();
+
+// Optional per-launch timing of the dominant kernel family with HIP events recorded on the launch
+// stream (bench.py's roofline leg). flops = 2*M*N*K per launch (algorithmic, padding excluded except
+// the 3/4 -> 32 input-channel pad of conv_in).
+struct KernelProfiler {
+  bool enabled = false;
+  std::vector<hipEvent_t> events;
+  std::vector<double> flops;
+  int used = 0;
+  void next_pair(hipEvent_t* a, hipEvent_t* b, double fl);
+  void collect(int* launches, double* total_ms, double* total_flops);
+  ~KernelProfiler();
+};
+extern KernelProfiler* g_conv_prof;
 
 // weight repack: fp32 [N][Cin][KH][KW] (torch conv / linear with KH=KW=1) -> bf16 [Npad][KH*KW*Cpad]
 // with zero padding; `geglu` interleaves value/gate rows in blocks of 32 (see conv_gemm.hip).

@@ -246,6 +246,15 @@ class Engine:
                                      ptr(self._f32(noise)) if noise is not None else None, C.c_uint64(seed)))
         return x
 
+    def prof_enable(self, on=True):
+        check(self.lib.cd_prof_enable(self.h, int(on)))
+
+    def prof_collect(self):
+        """(launches, total_ms, total_flops) of the implicit-GEMM kernel since prof_enable."""
+        n, ms, fl = C.c_int(), C.c_double(), C.c_double()
+        check(self.lib.cd_prof_collect(self.h, C.byref(n), C.byref(ms), C.byref(fl)))
+        return n.value, ms.value, fl.value
+
     def workspace_high_water(self):
         v = C.c_size_t()
         check(self.lib.cd_engine_workspace_high_water(self.h, C.byref(v)))

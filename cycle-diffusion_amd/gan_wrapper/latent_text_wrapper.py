@@ -1,0 +1,170 @@
+"""Text-conditioned latent wrappers on the HIP engine: drop-ins for
+  SDStochasticTextWrapper          model/gan_wrapper/stable_diffusion_stochastic_text_wrapper.py:102-253
+  LatentDiffStochasticTextWrapper  model/gan_wrapper/latentdiff_stochastic_text_wrapper.py
+Same constructor kwargs (the [gan] section of config/experiments/*.cfg), same
+encode(image, encode_text) -> z_ensemble and forward(z_ensemble, original_img, encode_text,
+decode_text) -> img contracts, same ensemble ordering (trial -> encoder scale -> skip_steps, then
+decoder scales) and z layout torch.stack(z_list, dim=1).view(bsz, -1).
+
+Out of scope here: the CLIP / BERT text encoders and the DirectionalCLIP ranker.
+Conditioning enters through `cond_stage` (a callable list[str] -> [B, 77, context_dim]); when no
+real encoder is plugged in, a deterministic stand-in embedding is used and SAYS SO in its name.
+"""
+import hashlib
+import os
+
+import torch
+
+from .. import _ffi, schedule
+from ..engine import kl_f8_vae_desc, ldm_text_unet_desc, sd_v1_unet_desc
+from ..runtime import get_engine, load_or_init_weights
+
+
+class StandInTextEmbedder:
+    """Deterministic N(0,1) embedding per string — NOT a text encoder; keeps tensor shapes and the
+    call pattern of get_learned_conditioning (ddpm.py:545-556) when no CLIP/BERT weights exist."""
+
+    def __init__(self, context_dim, length=77):
+        self.context_dim, self.length = context_dim, length
+
+    def __call__(self, texts):
+        out = []
+        for t in texts:
+            seed = int.from_bytes(hashlib.sha256(t.encode("utf-8")).digest()[:8], "little") % (2 ** 63)
+            g = torch.Generator().manual_seed(seed)
+            out.append(torch.randn(self.length, self.context_dim, generator=g))
+        return torch.stack(out, 0)
+
+
+class _LatentStochasticTextWrapper(torch.nn.Module):
+    # subclass constants
+    UNET_DESC = None
+    RESOLUTION = None
+    SAMPLE_POSTERIOR = True
+    LINEAR_START, LINEAR_END = 0.00085, 0.0120
+    SCALE_FACTOR = 0.18215
+
+    def __init__(self, source_model_type, custom_steps, eta, white_box_steps, skip_steps,
+                 encoder_unconditional_guidance_scales=None, decoder_unconditional_guidance_scales=None,
+                 n_trials=None, cond_stage=None, ranker=None, device=None):
+        super().__init__()
+        self.encoder_unconditional_guidance_scales = encoder_unconditional_guidance_scales
+        self.decoder_unconditional_guidance_scales = decoder_unconditional_guidance_scales
+        self.n_trials = n_trials
+        self.eta, self.custom_steps = eta, custom_steps
+        self.white_box_steps, self.skip_steps = white_box_steps, skip_steps
+        self.resolution = self.RESOLUTION
+        self.engine = get_engine(device)
+        udesc = self.UNET_DESC()
+        self.channels, self.image_size = udesc.in_channels, udesc.image_size
+        self.unet = self.engine.create_net(udesc)
+        self.vae = self.engine.create_net(kl_f8_vae_desc())
+        ckpt = self.checkpoint_path(source_model_type)
+        self.weights_origin = load_or_init_weights(self.engine, ckpt, {
+            self.unet: "model.diffusion_model.", self.vae: "first_stage_model."})
+        self.cond_stage = cond_stage or StandInTextEmbedder(udesc.context_dim)
+        self.ranker = ranker
+        self.alphas_cumprod = schedule.latent_alphas_cumprod(1000, self.LINEAR_START, self.LINEAR_END)
+        # `next(self.parameters()).device` must work (sd_wrapper:251-253) and DDP must be able to wrap us
+        self._anchor = torch.nn.Parameter(torch.zeros(1, device=self.engine.device), requires_grad=True)
+
+    # ---- conditioning (sd_wrapper:28-36)
+    def get_condition(self, text, bs):
+        assert isinstance(text, list) and isinstance(text[0], str)
+        uc = self.cond_stage(bs * [""]).to(self.device, torch.float32)
+        c = self.cond_stage(text).to(self.device, torch.float32)
+        return c, uc
+
+    def _schedule(self):
+        return schedule.DDIMSchedule(self.alphas_cumprod, self.custom_steps, self.eta)
+
+    # ---- encode (sd_wrapper:169-206)
+    def encode(self, image, encode_text):
+        image = (image - 0.5) * 2.0
+        assert image.shape[2] == image.shape[3] == self.resolution
+        image = image.to(self.device, torch.float32)
+        bsz = image.shape[0]
+        noise = None
+        if self.SAMPLE_POSTERIOR:
+            # DiagonalGaussianDistribution.sample draws on the CPU and moves (distributions.py:36)
+            h = self.resolution // 8
+            noise = torch.randn((bsz, self.channels, h, h)).to(self.device)
+        x0 = self.engine.vae_encode(self.vae, image, noise=noise, sample=self.SAMPLE_POSTERIOR,
+                                    scale=self.SCALE_FACTOR)
+        sch = self._schedule()
+        z_ensemble = []
+        for _trial in range(self.n_trials):
+            for enc_scale in self.encoder_unconditional_guidance_scales:
+                for skip in self.skip_steps:
+                    c, uc = self.get_condition(encode_text, bsz)
+                    assert self.eta > 0
+                    K = len(sch) - skip
+                    n_loop = min(K, self.white_box_steps - skip - 1) if self.white_box_steps != -1 else 0
+                    assert n_loop == K, "white_box_steps shorter than the chain is not used by the reference configs"
+                    # draw order of _ddpm_ddim_encoding: randn_like(x0) then K-1 x randn(shape) (ddim.py:479,599)
+                    nz = torch.randn((K,) + tuple(x0.shape), device=self.device)
+                    z = self.engine.dpm_encode(self.unet, _ffi.CD_SCHED_DDIM, x0, sch.coef_encode(skip), ctx_c=c,
+                                               ctx_uc=uc, guidance=float(enc_scale), noise=nz, last_uses_x0=True)
+                    z_ensemble.append(z.view(bsz, -1))
+        return z_ensemble
+
+    # ---- generate (sd_wrapper:142-167)
+    def generate(self, z_ensemble, decode_text):
+        img_ensemble = []
+        sch = self._schedule()
+        for i, z in enumerate(z_ensemble):
+            skip = self.skip_steps[i % len(self.skip_steps)]
+            bsz = z.shape[0]
+            zz = z.view(bsz, self.white_box_steps - skip, self.channels, self.image_size, self.image_size)
+            for dec_scale in self.decoder_unconditional_guidance_scales:
+                c, uc = self.get_condition(decode_text, bsz)
+                x = self.engine.ddim_decode(self.unet, _ffi.CD_SCHED_DDIM, zz.contiguous(), sch.coef_decode(skip),
+                                            ctx_c=c, ctx_uc=uc, guidance=float(dec_scale))
+                # decode_first_stage, then post_process (x+1)/2 fused into the final layout kernel
+                img_ensemble.append(self.engine.vae_decode(self.vae, x, scale=self.SCALE_FACTOR, out_mul=0.5,
+                                                           out_add=0.5))
+        return img_ensemble
+
+    def forward(self, z_ensemble, original_img, encode_text, decode_text):
+        img_ensemble = self.generate(z_ensemble, decode_text)
+        assert len(img_ensemble) == len(self.decoder_unconditional_guidance_scales) * \
+            len(self.encoder_unconditional_guidance_scales) * len(self.skip_steps) * self.n_trials
+        if len(img_ensemble) == 1:
+            return img_ensemble[0]
+        if self.ranker is None:
+            raise NotImplementedError(
+                "ensemble of %d candidates needs a DirectionalCLIP ranker (model/energy/clean_clip.py) — out of "
+                "scope for the hot path; pass ranker=callable(img, original_img, encode_text, decode_text)"
+                % len(img_ensemble))
+        scores = torch.stack([self.ranker(img, original_img, encode_text, decode_text) for img in img_ensemble], dim=1)
+        best = torch.argmax(scores, dim=1)  # per-sample argmax over the ensemble (sd_wrapper:228-235)
+        return torch.stack([img_ensemble[best[b].item()][b] for b in range(scores.shape[0])], dim=0)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+
+class SDStochasticTextWrapper(_LatentStochasticTextWrapper):
+    """gan_type = SDStochasticText (v1-inference.yaml; 512 px; posterior SAMPLED, ddpm.py:538)."""
+    UNET_DESC = staticmethod(sd_v1_unet_desc)
+    RESOLUTION = 512
+    SAMPLE_POSTERIOR = True
+
+    @staticmethod
+    def checkpoint_path(source_model_type):  # sd_wrapper:24
+        return os.path.join("ckpts", "stable_diffusion", source_model_type)
+
+
+class LatentDiffStochasticTextWrapper(_LatentStochasticTextWrapper):
+    """gan_type = LatentDiffStochasticText (txt2img-1p4B-eval.yaml; 256 px; posterior MEAN,
+    model/lib/latentdiff/ldm/models/diffusion/ddpm.py:535-538; linear schedule 0.00085..0.012)."""
+    UNET_DESC = staticmethod(ldm_text_unet_desc)
+    RESOLUTION = 256
+    SAMPLE_POSTERIOR = False
+
+    @staticmethod
+    def checkpoint_path(source_model_type):  # latentdiff_stochastic_text_wrapper.py:20-23
+        if source_model_type != "text2img-large":
+            raise ValueError(source_model_type)
+        return os.path.join("ckpts", "ldm_models", source_model_type, "model.ckpt")

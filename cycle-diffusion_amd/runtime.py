@@ -1,0 +1,41 @@
+"""Per-process engine registry and weight provisioning."""
+import os
+import warnings
+
+import torch
+
+from .engine import Engine
+
+_ENGINES = {}
+
+
+def get_engine(device=None):
+    """One engine (= one HIP stream + workspace) per device per process: one process per GPU."""
+    if device is None:
+        device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+    key = str(torch.device(device))
+    if key not in _ENGINES:
+        _ENGINES[key] = Engine(key)
+    return _ENGINES[key]
+
+
+def load_or_init_weights(engine, ckpt_path, nets_and_prefixes, seed=0):
+    """Load a reference checkpoint by its state_dict names (txt2img.py:25-42: pl_sd["state_dict"];
+    ddpm_ddim_wrapper.py:378-379: plain dict). There are no checkpoints in this tree (ckpts/ is empty,
+    SURVEY.md §0): unless CYCLEDIFF_SYNTHETIC_WEIGHTS=0, missing files fall back to seeded synthetic
+    weights (identical on every rank) so configs still run end to end."""
+    if ckpt_path and os.path.exists(ckpt_path):
+        sd = torch.load(ckpt_path, map_location="cpu")
+        if isinstance(sd, dict) and "state_dict" in sd:
+            sd = sd["state_dict"]
+        for net, prefix in nets_and_prefixes.items():
+            n, first = engine.load_state_dict(net, sd, prefix=prefix, strict=True)
+            if n:
+                raise KeyError("checkpoint %s lacks %d tensors, first: %s" % (ckpt_path, n, first))
+        return ckpt_path
+    if os.environ.get("CYCLEDIFF_SYNTHETIC_WEIGHTS", "1") == "0":
+        raise FileNotFoundError(ckpt_path)
+    warnings.warn("checkpoint %s not found: using seeded synthetic weights" % ckpt_path)
+    for i, net in enumerate(nets_and_prefixes):
+        engine.random_init(net, seed=seed + i)
+    return "synthetic(seed=%d)" % seed

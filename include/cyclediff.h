@@ -58,11 +58,17 @@ typedef struct cd_step_coef {
 
 const char* cd_last_error(void);
 int cd_version(void);
+/* 16-bit storage format of activations / packed weights inside the engine: 1 = IEEE fp16, 0 = bfloat16 */
+int cd_act_format(void);
 
 /* engine lifetime; `hip_stream` is a hipStream_t (0 = default stream) */
 int cd_engine_create(void* hip_stream, size_t workspace_bytes, cd_handle* out);
 int cd_engine_destroy(cd_handle h);
 int cd_engine_workspace_high_water(cd_handle h, size_t* bytes);
+/* per-launch timing of the implicit-GEMM kernel family with HIP events on the engine's stream
+ * (bench.py roofline leg): enable, run, then collect launches / summed ms / summed 2*M*N*K flops */
+int cd_prof_enable(cd_handle h, int on);
+int cd_prof_collect(cd_handle h, int* launches, double* total_ms, double* total_flops);
 
 /* networks: build from a descriptor, then load weights by the reference's state_dict names
  * (replaces load_model_from_config, model/lib/stable_diffusion/txt2img.py:25-42, and

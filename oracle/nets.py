@@ -312,10 +312,15 @@ def ho_unet(sd, cfg, x, t):
 
 
 # ----------------------------------------------------------------------------- deterministic synthetic weights
-def synth_state_dict(named_shapes, seed, zero_free=True):
-    """Seeded weights from a (name, shape) list, independent of any module class so fixtures can be
-    regenerated without the reference: matrices ~ N(0, 1/fan_in), norm gains ~ 1, biases small.
-    (The reference's zero_module tensors would make eps_hat == 0; every tensor is drawn non-zero.)"""
+ZERO_MODULE_SUFFIXES = ("out_layers.3.weight", "proj_out.weight", "out.2.weight")
+
+
+def synth_state_dict(named_shapes, seed):
+    """Seeded synthetic weights from a (name, shape) list — independent of any module class, so
+    fixtures can be rebuilt without the reference. Scales follow SURVEY.md §8(d): torch's default-init
+    scale for matrices (std 1/sqrt(3 fan_in)), and every tensor the reference creates with
+    zero_module() (ResBlock out conv, transformer / attention proj_out, U-Net out conv) drawn from
+    N(0, 0.02^2) instead of zeros (otherwise eps_hat == 0); norm gains ~ 1, biases small."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
     for name, shape in named_shapes:
@@ -328,5 +333,6 @@ def synth_state_dict(named_shapes, seed, zero_free=True):
             fan_in = 1
             for s in shape[1:]:
                 fan_in *= s
-            sd[name] = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+            std = 0.02 if name.endswith(ZERO_MODULE_SUFFIXES) else 1.0 / math.sqrt(3.0 * fan_in)
+            sd[name] = torch.randn(shape, generator=g) * std
     return sd

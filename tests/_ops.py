@@ -9,8 +9,9 @@ from cycle_diffusion_amd._ffi import check, ptr
 
 
 def bf16_round(t):
-    """Round an fp32 tensor to the nearest bf16 value (what the engine stores)."""
-    return t.to(torch.bfloat16).to(torch.float32)
+    """Round an fp32 tensor to the engine's 16-bit storage format (fp16 by default, cd_act_format())."""
+    dt = torch.float16 if _ffi.load_library().cd_act_format() == 1 else torch.bfloat16
+    return t.to(dt).to(torch.float32)
 
 
 def dev(t):

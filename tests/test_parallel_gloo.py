@@ -1,0 +1,57 @@
+"""CPU, world_size 2 over gloo: the N>1 path of the benchmark / model API — contiguous sharding of
+the triplets and the single per-step all-gather — reproduces the single-process batch order
+(trainer/trainer.py:43-61, 288-293)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cycle_diffusion_amd.parallel import gather_outputs, shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_items, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = torch.arange(n_items * 6, dtype=torch.float32).view(n_items, 2, 3)
+    lo, hi = shard_range(n_items, world, rank)
+    local_in = full[lo:hi]
+    local_out = local_in * 2 + 1                       # stand-in for the per-rank translation
+    (orig, img), loss = gather_outputs((local_in, local_out), torch.zeros(hi - lo))
+    ok = torch.equal(orig, full) and torch.equal(img, full * 2 + 1) and loss.shape[0] == n_items
+    q.put((rank, bool(ok), lo, hi))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_ranges_partition_the_batch():
+    for n, w in ((8, 2), (64, 8), (32, 8), (4, 1)):
+        spans = [shard_range(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+
+
+def test_gather_reproduces_global_order_world2():
+    world, n_items = 2, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res), res
+    assert sorted((lo, hi) for _, _, lo, hi in res) == [(0, 4), (4, 8)]
