@@ -75,7 +75,8 @@ class ParamStore {
   float* new_vec(int n, float init = 0.f);
   // declare reference tensors and where their rows go
   ParamDecl& declare(const std::string& name, std::vector<int64_t> shape);
-  void conv_weight(const std::string& name, ConvW* c);  // whole tensor -> whole ConvW
+  // whole tensor -> whole ConvW; ref_ndim = rank of the reference tensor (2 Linear, 3 Conv1d, 4 Conv2d; 0 = auto)
+  void conv_weight(const std::string& name, ConvW* c, int ref_ndim = 0);
   void conv_bias(const std::string& name, ConvW* c);
   void conv_rows(const std::string& name, std::vector<int64_t> shape, ConvW* c, int dst_row0, int rows,
                  int src_base, int grp, int grp_stride);

@@ -64,9 +64,11 @@ ParamDecl& ParamStore::declare(const std::string& name, std::vector<int64_t> sha
   by_name_[name] = d;
   return *d;
 }
-void ParamStore::conv_weight(const std::string& name, ConvW* c) {
+void ParamStore::conv_weight(const std::string& name, ConvW* c, int ref_ndim) {
   std::vector<int64_t> shape;
-  if (c->KH == 1 && c->KW == 1) shape = {c->N, c->Cin};  // Linear or 1x1 conv: accept both ranks at load
+  if (ref_ndim == 0) ref_ndim = (c->KH == 1 && c->KW == 1) ? 2 : 4;
+  if (ref_ndim == 2) shape = {c->N, c->Cin};
+  else if (ref_ndim == 3) shape = {c->N, c->Cin, 1};
   else shape = {c->N, c->Cin, c->KH, c->KW};
   ParamDecl& d = declare(name, shape);
   PackTarget t; t.kind = PackTarget::MATRIX_BF16; t.conv = c; t.dst_row0 = 0; t.rows = c->N;

@@ -23,7 +23,7 @@ GNW mk_gn(ParamStore& ps, const std::string& pfx, int C) {
 }
 ConvW* mk_conv(ParamStore& ps, const std::string& pfx, int N, int Cin, int k, bool bias = true) {
   ConvW* c = ps.new_conv(N, Cin, k, k, bias);
-  ps.conv_weight(pfx + ".weight", c);
+  ps.conv_weight(pfx + ".weight", c, 4);
   if (bias) ps.conv_bias(pfx + ".bias", c);
   return c;
 }
@@ -54,12 +54,12 @@ AtW mk_at(ParamStore& ps, const std::string& pfx, int C) {
   AtW a; a.C = C;
   a.norm = mk_gn(ps, pfx + ".norm", C);
   a.qk = ps.new_conv(2 * C, C, 1, 1, true);
-  ps.conv_rows(pfx + ".q.weight", {C, C}, a.qk, 0, C, 0, C, 0);
-  ps.conv_rows(pfx + ".k.weight", {C, C}, a.qk, C, C, 0, C, 0);
+  ps.conv_rows(pfx + ".q.weight", {C, C, 1, 1}, a.qk, 0, C, 0, C, 0);
+  ps.conv_rows(pfx + ".k.weight", {C, C, 1, 1}, a.qk, C, C, 0, C, 0);
   ps.bias_rows(pfx + ".q.bias", C, a.qk->b, 0, C, 0, C, 0);
   ps.bias_rows(pfx + ".k.bias", C, a.qk->b, C, C, 0, C, 0);
   a.v = ps.new_conv(C, C, 1, 1, false);
-  ps.conv_weight(pfx + ".v.weight", a.v);
+  ps.conv_weight(pfx + ".v.weight", a.v, 4);
   a.vbias = ps.new_vec(C);
   ps.vec(pfx + ".v.bias", a.vbias, C);
   a.proj = mk_conv(ps, pfx + ".proj_out", C, C, 1);

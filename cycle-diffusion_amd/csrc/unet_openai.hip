@@ -95,9 +95,11 @@ LNW make_ln(ParamStore& ps, const std::string& pfx, int C) {
   ps.vec(pfx + ".bias", g.b, C);
   return g;
 }
-ConvW* make_conv(ParamStore& ps, const std::string& pfx, int N, int Cin, int k, bool bias, bool geglu = false) {
+// ref_ndim: rank of the reference weight tensor (2 = nn.Linear, 3 = Conv1d, 4 = Conv2d)
+ConvW* make_conv(ParamStore& ps, const std::string& pfx, int N, int Cin, int k, bool bias, bool geglu = false,
+                 int ref_ndim = 4) {
   ConvW* c = ps.new_conv(N, Cin, k, k, bias, geglu);
-  ps.conv_weight(pfx + ".weight", c);
+  ps.conv_weight(pfx + ".weight", c, ref_ndim);
   if (bias) ps.conv_bias(pfx + ".bias", c);
   return c;
 }
@@ -131,14 +133,14 @@ int UNetOpenAI::add_st(const std::string& pfx, int C, int heads, int dh) {
   s.qk1 = params.new_conv(2 * C, C, 1, 1, false);
   params.conv_rows(tb + ".attn1.to_q.weight", {C, C}, s.qk1, 0, C, 0, C, 0);
   params.conv_rows(tb + ".attn1.to_k.weight", {C, C}, s.qk1, C, C, 0, C, 0);
-  s.v1 = make_conv(params, tb + ".attn1.to_v", C, C, 1, false);
-  s.o1 = make_conv(params, tb + ".attn1.to_out.0", C, C, 1, true);
-  s.q2 = make_conv(params, tb + ".attn2.to_q", C, C, 1, false);
-  s.k2 = make_conv(params, tb + ".attn2.to_k", C, s.ctx, 1, false);
-  s.v2 = make_conv(params, tb + ".attn2.to_v", C, s.ctx, 1, false);
-  s.o2 = make_conv(params, tb + ".attn2.to_out.0", C, C, 1, true);
-  s.ff1 = make_conv(params, tb + ".ff.net.0.proj", 8 * C, C, 1, true, /*geglu=*/true);
-  s.ff2 = make_conv(params, tb + ".ff.net.2", C, 4 * C, 1, true);
+  s.v1 = make_conv(params, tb + ".attn1.to_v", C, C, 1, false, false, 2);
+  s.o1 = make_conv(params, tb + ".attn1.to_out.0", C, C, 1, true, false, 2);
+  s.q2 = make_conv(params, tb + ".attn2.to_q", C, C, 1, false, false, 2);
+  s.k2 = make_conv(params, tb + ".attn2.to_k", C, s.ctx, 1, false, false, 2);
+  s.v2 = make_conv(params, tb + ".attn2.to_v", C, s.ctx, 1, false, false, 2);
+  s.o2 = make_conv(params, tb + ".attn2.to_out.0", C, C, 1, true, false, 2);
+  s.ff1 = make_conv(params, tb + ".ff.net.0.proj", 8 * C, C, 1, true, /*geglu=*/true, 2);
+  s.ff2 = make_conv(params, tb + ".ff.net.2", C, 4 * C, 1, true, false, 2);
   st_.push_back(s);
   return (int)st_.size() - 1;
 }
@@ -152,13 +154,13 @@ int UNetOpenAI::add_ab(const std::string& pfx, int C, int heads) {
   a.v = params.new_conv(C, C, 1, 1, false);
   a.vbias = params.new_vec(C);
   const std::string wn = pfx + ".qkv.weight", bn = pfx + ".qkv.bias";
-  params.conv_rows(wn, {3 * C, C}, a.qk, 0, C, 0, ch, 3 * ch);
-  params.conv_rows(wn, {3 * C, C}, a.qk, C, C, ch, ch, 3 * ch);
-  params.conv_rows(wn, {3 * C, C}, a.v, 0, C, 2 * ch, ch, 3 * ch);
+  params.conv_rows(wn, {3 * C, C, 1}, a.qk, 0, C, 0, ch, 3 * ch);
+  params.conv_rows(wn, {3 * C, C, 1}, a.qk, C, C, ch, ch, 3 * ch);
+  params.conv_rows(wn, {3 * C, C, 1}, a.v, 0, C, 2 * ch, ch, 3 * ch);
   params.bias_rows(bn, 3 * C, a.qk->b, 0, C, 0, ch, 3 * ch);
   params.bias_rows(bn, 3 * C, a.qk->b, C, C, ch, ch, 3 * ch);
   params.bias_rows(bn, 3 * C, a.vbias, 0, C, 2 * ch, ch, 3 * ch);
-  a.proj = make_conv(params, pfx + ".proj_out", C, C, 1, true);
+  a.proj = make_conv(params, pfx + ".proj_out", C, C, 1, true, false, 3);
   ab_.push_back(a);
   return (int)ab_.size() - 1;
 }
