@@ -29,13 +29,26 @@ F_IMG = F_VAE_ENC + N_STEPS * F_UNET + N_STEPS * 2 * F_UNET + F_VAE_DEC   # 242.
 PEAK_TFLOPS = 2500.0  # dense 16-bit MFMA peak (MI355X_MICROARCH.md)
 
 
+def host_cores():
+    """CPU cores this process may actually use: min(affinity mask, cgroup-v2 quota). (The GPU box shows
+    256 logical CPUs but caps the container at 16; oversubscribing a quota throttles everything.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(eng, un, vn, seed=0):
     """The CPU oracle (torch fp32 restatement of the reference path, oracle/) timed on this box's host
     cores on a bounded sample: one SD U-Net forward at batch 1 and one at batch 2 (the CFG pair), one
     VAE encode and one decode at 512x512; extrapolated linearly to 99 + 99 steps (all steps cost the
     same)."""
     from oracle import nets
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     ucfg = nets.OpenAIUNetCfg(in_channels=4, out_channels=4, model_channels=320, num_res_blocks=2,
                               channel_mult=(1, 2, 4, 4), attn_ds=(4, 2, 1), num_heads=8,
@@ -70,6 +83,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
+    torch.set_num_threads(host_cores())  # host-side weight synthesis / oracle: stay inside the CPU quota
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -9,8 +9,24 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _host_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:  # the oracle runs on the host: stay inside the container's CPU quota
+        import torch
+        torch.set_num_threads(_host_cores())
+    except Exception:
+        pass
 
 
 def _has_gpu():
