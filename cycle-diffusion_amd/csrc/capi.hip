@@ -1,5 +1,6 @@
 // extern "C" boundary (include/cyclediff.h): engine lifetime, weight loading, the sampler loops
 // (DPM-Encoder / coupled decode) and single-kernel entry points used by the parity tests.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -72,6 +73,14 @@ int cd_engine_create(void* hip_stream, size_t workspace_bytes, cd_handle* out) {
   h->arena.init(workspace_bytes);
   HIP_CHECK(hipMalloc((void**)&h->zeros, 4096));
   HIP_CHECK(hipMemset(h->zeros, 0, 4096));
+  {  // implicit-GEMM autotuner (CYCLEDIFF_AUTOTUNE=0 turns it off)
+    const char* e = getenv("CYCLEDIFF_AUTOTUNE");
+    if (!(e && e[0] == '0') && !g_conv_tuner.scratch) {
+      g_conv_tuner.scratch_bytes = (size_t)768 << 20;
+      HIP_CHECK(hipMalloc(&g_conv_tuner.scratch, g_conv_tuner.scratch_bytes));
+      g_conv_tuner.enabled = true;
+    }
+  }
   h->gn_partial_floats = (size_t)1 << 20;
   HIP_CHECK(hipMalloc((void**)&h->gn_partial, h->gn_partial_floats * sizeof(float)));
   *out = h.release();
@@ -573,6 +582,57 @@ __global__ void k_probe_tr(float* out) {
   out[lane * 4 + 3] = bf2f((bf16_t)(v.y >> 16));
 }
 }  // namespace
+
+namespace {
+__global__ void k_fill_hash16(bf16_t* p, int64_t n, uint32_t seed, float scale) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t x = (uint32_t)i * 2654435761u + seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    p[i] = f2bf(((float)(x & 0xffff) / 32768.0f - 1.0f) * scale);  // uniform [-scale, scale): full-range data
+  }
+}
+}  // namespace
+
+// Micro-benchmark of one conv / GEMM shape on synthetic full-range data: `iters` back-to-back launches
+// between two HIP events on the engine stream. ms_out = average per launch.
+extern "C" int cd_op_bench_conv(cd_handle h, int B, int H, int W, int C0, int C1, int N, int k, int stride,
+                                int up, int act, int tile, int iters, float* ms_out) {
+  CD_API_BEGIN
+  CD_CHECK(h && ms_out && iters > 0, "bad argument");
+  const size_t mk = h->arena.mark();
+  Ctx c = h->ctx();
+  ConvW w;
+  w.N = N; w.Cin = C0 + C1; w.KH = k; w.KW = k; w.Cpad = round_up(C0 + C1, 32); w.Npad = round_up(N, 128);
+  w.geglu = (act == ACT_GEGLU);
+  const size_t wn = (size_t)w.Npad * w.Ktot();
+  w.w = (bf16_t*)h->arena.alloc(wn * 2);
+  w.b = (float*)h->arena.alloc((size_t)w.Npad * 4);
+  HIP_CHECK(hipMemsetAsync(w.b, 0, (size_t)w.Npad * 4, h->st));
+  hipLaunchKernelGGL(k_fill_hash16, dim3(1024), dim3(256), 0, h->st, w.w, (int64_t)wn, 17u,
+                     1.0f / sqrtf((float)w.Ktot()));
+  Act a0 = alloc_act(c, B, H, W, C1 ? C0 : round_up(C0, 32));
+  hipLaunchKernelGGL(k_fill_hash16, dim3(1024), dim3(256), 0, h->st, a0.p, (int64_t)a0.rows() * a0.C, 3u, 1.0f);
+  Act a1;
+  if (C1) {
+    a1 = alloc_act(c, B, H, W, C1);
+    hipLaunchKernelGGL(k_fill_hash16, dim3(1024), dim3(256), 0, h->st, a1.p, (int64_t)a1.rows() * a1.C, 5u, 1.0f);
+  }
+  ConvOpts o; o.stride = stride; o.pad = k / 2; o.up = up != 0; o.act = (act == ACT_GEGLU) ? ACT_NONE : act; o.tile = tile;
+  const size_t mk2 = h->arena.mark();
+  conv_fwd(c, w, a0, C1 ? &a1 : nullptr, o);  // warm-up
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+  HIP_CHECK(hipEventRecord(e0, h->st));
+  for (int i = 0; i < iters; ++i) { h->arena.release(mk2); conv_fwd(c, w, a0, C1 ? &a1 : nullptr, o); }
+  HIP_CHECK(hipEventRecord(e1, h->st));
+  HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / iters;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  h->arena.release(mk);
+  CD_API_END
+}
 
 extern "C" int cd_op_probe(cd_handle h, int which, const void* in, void* out, size_t n) {
   CD_API_BEGIN

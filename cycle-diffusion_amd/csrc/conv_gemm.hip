@@ -1,50 +1,74 @@
-// Implicit-GEMM convolution / GEMM for gfx950: bf16 MFMA 32x32x16, fp32 accumulate.
+// Implicit-GEMM convolution / GEMM for gfx950: 16-bit MFMA 32x32x16 (fp16 or bf16), fp32 accumulate.
 //
 // One kernel family covers every contraction on the hot path:
 // 3x3 s1 p1 conv, 3x3 s2 conv (U-Net Downsample p=1, openaimodel.py:134-160; VAE pad(0,1,0,1),
 // model.py:72-76), 1x1 conv, nn.Linear, and batched Q.K^T / P.V for the single-head AttnBlock
-// (model.py:178-202). Activations are NHWC bf16, so a K-slice of one filter tap is a contiguous
+// (model.py:178-202). Activations are NHWC 16-bit, so a K-slice of one filter tap is a contiguous
 // run of channels; the skip-connection concat (openaimodel.py:736) is a second source pointer in
 // the K loop and nearest-x2 upsampling (openaimodel.py:115) is folded into the gather address.
 //
-// Structure (CDNA4): 256 threads = 4 waves; BMxBN tile, BK-deep K steps; both operands are staged
-// HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double buffered, one barrier per
-// K step; LDS rows are XOR-swizzled on the *source* side so ds_read_b128 fragment reads are
-// conflict free; accumulators go through LDS in the epilogue so global stores are 16 B per lane
-// with bias / time-embedding / residual / SiLU / GELU / GEGLU fused.
+// Structure (CDNA4): 4 or 8 waves per workgroup; BMxBN tile, BK-deep K steps; both operands are
+// staged HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip) into an NSTAGE-deep LDS
+// ring; the wait for a tile is a COUNTED s_waitcnt vmcnt(N) (younger tiles stay in flight across the
+// single workgroup barrier per K step); LDS rows are XOR-swizzled on the *source* side so
+// ds_read_b128 fragment reads are conflict free; accumulators go through LDS in the epilogue so
+// global stores are 16 B per lane with bias / time-embedding / residual / SiLU / GELU / GEGLU fused.
+// Per-element reduction order is k-ascending for every tile configuration, so results do not
+// depend on which configuration (or batch size) is chosen.
+#include <string.h>
+
+#include <map>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace cd {
 
-namespace {
+namespace gemm_detail {
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, int NSTAGE>
 struct TileCfg {
-  static constexpr int CPR = BK / 8;         // 16-byte chunks per LDS row
-  static constexpr int RPI = 64 / CPR;       // rows covered by one wave-wide glds
-  static constexpr int A_IPW = BM / RPI / 4; // glds instructions per wave per K step (A)
-  static constexpr int B_IPW = BN / RPI / 4;
+  static constexpr int NW = WM * WN;             // waves per workgroup
+  static constexpr int CPR = BK / 8;             // 16-byte chunks per LDS row
+  static constexpr int RPI = 64 / CPR;           // rows covered by one wave-wide glds
+  static constexpr int A_IPW = BM / RPI / NW;    // glds instructions per wave per K step (A)
+  static constexpr int B_IPW = BN / RPI / NW;
+  static constexpr int LPT = A_IPW + B_IPW;      // loads per wave per tile (vmcnt unit)
   static constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
   static constexpr int MT = TM / 32, NT = TN / 32;
   static constexpr int KS = BK / 16;
   static constexpr int SWZ_SHIFT = (CPR == 8) ? 1 : 2;
-  static constexpr int EPI_LD = TN + 4;      // fp32 row stride of the epilogue staging tile
-  static constexpr int STAGE_BYTES = (BM + BN) * BK * 2 * 2;
-  static constexpr int EPI_BYTES = 4 * TM * EPI_LD * 4;
-  static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
-  static_assert(WM * WN == 4, "4 waves");
-  static_assert(A_IPW >= 1 && B_IPW >= 1, "tile too small for 4 waves");
+  static constexpr int EPI_LD = TN + 4;          // fp32 row stride of the epilogue staging tile
+  static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int EPI_BYTES = NW * TM * EPI_LD * 4;
+  static constexpr int LDS_BYTES = STAGE_BYTES * NSTAGE > EPI_BYTES ? STAGE_BYTES * NSTAGE : EPI_BYTES;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static_assert(A_IPW >= 1 && B_IPW >= 1, "tile too small for the wave count");
+  static_assert(A_IPW * RPI * NW == BM && B_IPW * RPI * NW == BN, "tile rows must split evenly over waves");
+  static_assert(MT >= 1 && NT >= 1, "wave tile");
+  static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
+  static_assert((NSTAGE - 2) * LPT <= 63, "vmcnt field");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int BM, int BN, int BK, int WM, int WN>
-__global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
-  using T = TileCfg<BM, BN, BK, WM, WN>;
-  constexpr int CPR = T::CPR, RPI = T::RPI, A_IPW = T::A_IPW, B_IPW = T::B_IPW;
-  constexpr int MT = T::MT, NT = T::NT, KS = T::KS, TM = T::TM, TN = T::TN;
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_barrier() {
+  // this wave's loads of the current tile have landed (N younger ones may still fly) -> workgroup barrier.
+  // One asm statement with a memory clobber: the compiler can neither move LDS accesses across it nor
+  // add its own vmcnt(0) drain in front of the barrier.
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins below: the host pass only needs the launch stub
+  using T = TileCfg<BM, BN, BK, WM, WN, NSTAGE>;
+  constexpr int CPR = T::CPR, RPI = T::RPI, A_IPW = T::A_IPW, B_IPW = T::B_IPW, NW = T::NW;
+  constexpr int MT = T::MT, NT = T::NT, KS = T::KS, TM = T::TM, TN = T::TN, LPT = T::LPT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -68,24 +92,42 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
   const int m0 = tm * BM, n0 = tn * BN;
   const int zb = blockIdx.z;
 
-  const bf16_t* src0 = p.src0 + (int64_t)zb * p.a_bs;
-  const bf16_t* src1 = p.src1 ? p.src1 + (int64_t)zb * p.a_bs : nullptr;
-  const bf16_t* wgt = p.wgt + (int64_t)zb * p.w_bs;
+  // ---- operand descriptors. Every staging load is `buffer_load_dwordx4 voff, rsrc, soff offen lds`:
+  // the per-lane byte offset `voff` is constant within one filter tap (recomputed only when the tap or
+  // the concat source changes), the K position inside the tap is the scalar `soff`, and rows that fall
+  // into the zero padding (or beyond M) carry an out-of-range offset, for which the buffer unit
+  // returns zeros into LDS. The K loop therefore issues no per-lane address arithmetic.
+  constexpr unsigned kRange = 0x7fffffffu, kInvalid = 0x80000000u;
+  const bf16_t* base0 = p.src0 + (int64_t)zb * p.a_bs;
+  const bf16_t* base1 = p.src1 ? p.src1 + (int64_t)zb * p.a_bs : base0;
+  const __amdgpu_buffer_rsrc_t rsw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.wgt + (int64_t)zb * p.w_bs), 0, kRange, 0x00020000);
 
   // ---- per-lane staging geometry
   const int srow = lane / CPR;   // row within a glds instruction
   const int pchunk = lane % CPR; // physical 16-B chunk this lane fills
-  int a_iy0[A_IPW], a_ix0[A_IPW], a_boff[A_IPW], a_lchunk[A_IPW];
+  int a_iy0[A_IPW], a_ix0[A_IPW], a_boff[A_IPW], a_lc8[A_IPW];
+  unsigned a_voff[A_IPW];
   const int HWo = p.Hout * p.Wout;
+  const bool pow2 = ((HWo & (HWo - 1)) == 0) && ((p.Wout & (p.Wout - 1)) == 0);
+  const int sh_hw = 31 - __builtin_clz(HWo), sh_w = 31 - __builtin_clz(p.Wout);
 #pragma unroll
   for (int i = 0; i < A_IPW; ++i) {
-    const int row = (i * 4 + wave) * RPI + srow;
+    const int row = (i * NW + wave) * RPI + srow;
     const int m = m0 + row;
-    a_lchunk[i] = pchunk ^ ((row >> T::SWZ_SHIFT) & (CPR - 1));
+    a_lc8[i] = (pchunk ^ ((row >> T::SWZ_SHIFT) & (CPR - 1))) * 8;
+    a_voff[i] = kInvalid;
     if (m < p.M) {
-      const int b = m / HWo;
-      const int rem = m - b * HWo;
-      const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+      int b, oy, ox;
+      if (pow2) {  // every layer of the reference networks: shifts instead of ~100-instruction divisions
+        b = m >> sh_hw;
+        const int rem = m & (HWo - 1);
+        oy = rem >> sh_w; ox = rem & (p.Wout - 1);
+      } else {
+        b = m / HWo;
+        const int rem = m - b * HWo;
+        oy = rem / p.Wout; ox = rem - oy * p.Wout;
+      }
       a_iy0[i] = oy * p.stride - p.pad_t;
       a_ix0[i] = ox * p.stride - p.pad_l;
       a_boff[i] = b * p.Hs * p.Ws;
@@ -95,50 +137,66 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
       a_boff[i] = 0;
     }
   }
-  const bf16_t* b_ptr[B_IPW];
+  unsigned b_voff[B_IPW];
 #pragma unroll
   for (int i = 0; i < B_IPW; ++i) {
-    const int row = (i * 4 + wave) * RPI + srow;
+    const int row = (i * NW + wave) * RPI + srow;
     const int lchunk = pchunk ^ ((row >> T::SWZ_SHIFT) & (CPR - 1));
     int nrow = n0 + row;
     if (nrow >= p.N) nrow = p.N - 1;  // clamp: duplicates a valid row, its outputs are masked
-    b_ptr[i] = wgt + (int64_t)nrow * (p.ldw ? p.ldw : p.Ktot) + lchunk * 8;
+    b_voff[i] = (unsigned)((nrow * (p.ldw ? p.ldw : p.Ktot) + lchunk * 8) * 2);
   }
 
   const int Ctot = p.C0 + p.C1;
   const int nk = p.Ktot / BK;
-  // K-step cursor (uniform): tap (kr, ks_) and channel offset kc within the concatenated channels
+  // K-step cursor (uniform): tap (kr, kss) and channel offset kc within the concatenated channels
   int kr = 0, kss = 0, kc = 0;
 
-  char* As = smem;
-  char* Bs = smem + 2 * BM * BK * 2;
+  char* As = smem;                       // [NSTAGE][BM*BK*2]
+  char* Bs = smem + NSTAGE * T::A_BYTES; // [NSTAGE][BN*BK*2]
 
-  auto stage = [&](int buf, int kt) {
-    const bf16_t* sp;
-    int ld, coff;
-    if (kc < p.C0) { sp = src0; ld = p.ld0; coff = kc; }
-    else { sp = src1; ld = p.ld1; coff = kc - p.C0; }
-#pragma unroll
-    for (int i = 0; i < A_IPW; ++i) {
-      int iy = a_iy0[i] + kr, ix = a_ix0[i] + kss;
-      const bool ok = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);
-      if (p.up) { iy >>= 1; ix >>= 1; }
-      const int pix = a_boff[i] + iy * p.Ws + ix;
-      const bf16_t* g = ok ? sp + (int64_t)pix * ld + coff + a_lchunk[i] * 8 : p.zeros + a_lchunk[i] * 8;
-      char* l = As + buf * (BM * BK * 2) + ((i * 4 + wave) * RPI) * (BK * 2);
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < B_IPW; ++i) {
-      const bf16_t* g = b_ptr[i] + (int64_t)kt * BK;
-      char* l = Bs + buf * (BN * BK * 2) + ((i * 4 + wave) * RPI) * (BK * 2);
-      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
-    }
-    // advance cursor
+  // ---- staging of one K tile, split in two so the loads can be spread over the MFMA segments:
+  // prepare() does all control flow (cursor advance, per-tap offset refresh), issue(idx) emits load #idx.
+  // Tiles past the end are issued with out-of-range offsets (zero fill into a dead ring slot), so every
+  // iteration has the same vmcnt footprint and the loop body is branch-free.
+  bool st_live = false;
+  int st_soffa = 0, st_soffb = 0;
+  const bf16_t* st_base = base0;
+  auto prepare = [&](int kt) {
+    st_live = kt < nk;
+    const int c_kc = kc, c_kr = kr, c_kss = kss;
     kc += BK;
     if (kc >= Ctot) {
       kc = 0;
       if (++kss >= p.KW) { kss = 0; ++kr; }
+    }
+    if (st_live && (c_kc == 0 || c_kc == p.C0)) {  // new filter tap / second concat source
+      const int ld = (c_kc < p.C0) ? p.ld0 : p.ld1;
+#pragma unroll
+      for (int i = 0; i < A_IPW; ++i) {
+        int iy = a_iy0[i] + c_kr, ix = a_ix0[i] + c_kss;
+        const bool ok = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);
+        if (p.up) { iy >>= 1; ix >>= 1; }
+        const int pix = a_boff[i] + iy * p.Ws + ix;
+        a_voff[i] = ok ? (unsigned)((pix * ld + a_lc8[i]) * 2) : kInvalid;
+      }
+    }
+    const bool first = c_kc < p.C0;
+    st_base = first ? base0 : base1;
+    st_soffa = (first ? c_kc : c_kc - p.C0) * 2;
+    st_soffb = st_live ? kt * (BK * 2) : 0;
+  };
+  auto issue = [&](int idx, int buf) {  // idx is a compile-time constant after unrolling
+    if (idx < A_IPW) {
+      const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)st_base, 0, kRange, 0x00020000);
+      char* l = As + buf * T::A_BYTES + ((idx * NW + wave) * RPI) * (BK * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lptr_t)l, 16, st_live ? a_voff[idx < A_IPW ? idx : 0] : kInvalid,
+                                               st_soffa, 0, 0);
+    } else {
+      const int i = idx - A_IPW;
+      char* l = Bs + buf * T::B_BYTES + ((i * NW + wave) * RPI) * (BK * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lptr_t)l, 16, st_live ? b_voff[i < B_IPW ? i : 0] : kInvalid,
+                                               st_soffb, 0, 0);
     }
   };
 
@@ -153,39 +211,60 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
   const int frow = lane & 31;  // fragment row within a 32-row MFMA tile
   const int fhalf = lane >> 5; // which 8-wide k half this lane feeds
 
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* Ab = As + cur * (BM * BK * 2);
-    const char* Bb = Bs + cur * (BN * BK * 2);
+  // ---- prologue: fill NSTAGE-1 ring slots
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      bf16x8 af[MT], bfr[NT];
+  for (int s = 0; s < NSTAGE - 1; ++s) {
+    prepare(s);
+#pragma unroll
+    for (int l = 0; l < LPT; ++l) issue(l, s);
+  }
+
+  int cur = 0;             // ring slot of tile kt
+  int nxt = NSTAGE - 1;    // ring slot the next prefetch goes to (= slot of tile kt-1)
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed when at most (NSTAGE-2) younger tiles (LPT loads each) are still in flight
+    wait_vmcnt_barrier<(NSTAGE - 2) * LPT>();
+    // every wave has passed the barrier => everyone finished reading slot `nxt` (tile kt-1): refill it
+    prepare(kt + NSTAGE - 1);
+    const char* Ab = As + cur * T::A_BYTES;
+    const char* Bb = Bs + cur * T::B_BYTES;
+    bf16x8 af[KS][MT], bfr[KS][NT];
+    auto read_frags = [&](int ks) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int row = wm * TM + i * 32 + frow;
         const int ch = (ks * 2 + fhalf) ^ ((row >> T::SWZ_SHIFT) & (CPR - 1));
-        af[i] = *(const bf16x8*)(Ab + row * (BK * 2) + ch * 16);
+        af[ks][i] = *(const bf16x8*)(Ab + row * (BK * 2) + ch * 16);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int row = wn * TN + j * 32 + frow;
         const int ch = (ks * 2 + fhalf) ^ ((row >> T::SWZ_SHIFT) & (CPR - 1));
-        bfr[j] = *(const bf16x8*)(Bb + row * (BK * 2) + ch * 16);
+        bfr[ks][j] = *(const bf16x8*)(Bb + row * (BK * 2) + ch * 16);
       }
+    };
+    // segment 0: fragments of the first two k-slices; then per k-slice one pinned segment with its share
+    // of the staging loads, the slice's MFMAs (independent accumulators) and the reads two slices ahead
+    read_frags(0);
+    if (KS > 1) read_frags(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int l = (ks * LPT) / KS; l < ((ks + 1) * LPT) / KS; ++l) issue(l, nxt);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = CD_MFMA_32x32x16(af[i], bfr[j], acc[i][j]);
+          acc[i][j] = CD_MFMA_32x32x16(af[ks][i], bfr[ks][j], acc[i][j]);
+      if (ks + 2 < KS) read_frags(ks + 2);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    nxt = cur;
+    cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy tail loads before LDS is reused
+  __syncthreads();  // all waves done with the ring before the epilogue reuses LDS
 
   // ---- epilogue: accumulators -> LDS (fp32, per-wave region) -> fused elementwise -> 16-B stores
   float* E = (float*)smem + wave * (TM * T::EPI_LD);
@@ -202,20 +281,27 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
   __syncthreads();
 
   const bool geglu = (p.act == ACT_GEGLU);
-  // GEGLU: packed columns come in blocks of 64 = [32 value | 32 gate] (launch_repack_weight);
+  // GEGLU: packed columns come in blocks of 64 = [32 value | 32 gate] (k_pack_rows);
   // only the value half produces output, at column (n/64)*32 + n%32.
   constexpr int VPR_FULL = TN / 8;
   const int vpr = geglu ? (TN / 16) : VPR_FULL;  // 8-wide vectors per row handled
   const int rpp = 64 / vpr;                      // rows per pass
   const int vr = lane / vpr, vc = lane % vpr;
   char* outp = (char*)p.out + (int64_t)zb * p.o_bs * (p.out_f32 ? 4 : 2);
+  // column-only quantities are the same for every row this lane handles: hoist them out of the row loop
+  const int col = geglu ? (vc / 4) * 64 + (vc % 4) * 8 : vc * 8;  // column inside the wave tile
+  const int n = n0 + wn * TN + col;                                // packed column
+  const int nvalid = (p.N - n) < 8 ? (p.N - n) : 8;
+  float bias_v[8], bias_g[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bias_v[e] = (p.bias && e < nvalid) ? p.bias[n + e] : 0.0f;
+    bias_g[e] = (geglu && p.bias) ? p.bias[n + 32 + e] : 0.0f;
+  }
   for (int r0 = 0; r0 < TM; r0 += rpp) {
     const int row = r0 + vr;
+    if (row >= TM) continue;
     const int m = m0 + wm * TM + row;
-    int col;  // column inside the wave tile
-    if (geglu) col = (vc / 4) * 64 + (vc % 4) * 8;
-    else col = vc * 8;
-    const int n = n0 + wn * TN + col;  // packed column
     if (m >= p.M || n >= p.N) continue;
     float v[8];
     {
@@ -224,11 +310,8 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
       v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
       v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
     }
-    const int nvalid = (p.N - n) < 8 ? (p.N - n) : 8;
-    if (p.bias) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += p.bias[n + e];
-    }
+    for (int e = 0; e < 8; ++e) v[e] += bias_v[e];
     int on = n;  // output column
     if (geglu) {
       float gt[8];
@@ -238,13 +321,14 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
       gt[4] = hi[0]; gt[5] = hi[1]; gt[6] = hi[2]; gt[7] = hi[3];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float gg = gt[e] + (p.bias ? p.bias[n + 32 + e] : 0.0f);
+        const float gg = gt[e] + bias_g[e];
         v[e] = v[e] * gelu_f(gg);
       }
       on = (n / 64) * 32 + (n % 64);
     } else {
       if (p.rowvec) {
-        const float* rv = p.rowvec + (int64_t)(m / p.rows_per_vec) * p.rowvec_ld + n;
+        const int rvi = (p.rows_per_vec >= p.M) ? 0 : m / p.rows_per_vec;  // shared timestep: one vector
+        const float* rv = p.rowvec + (int64_t)rvi * p.rowvec_ld + n;
 #pragma unroll
         for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += rv[e];
       }
@@ -287,25 +371,75 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmParams p) {
       }
     }
   }
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, int NSTAGE>
 void launch_cfg(hipStream_t st, const ConvGemmParams& p) {
-  using T = TileCfg<BM, BN, BK, WM, WN>;
+  using T = TileCfg<BM, BN, BK, WM, WN, NSTAGE>;
   static bool attr_set = false;
-  auto kern = k_conv_gemm<BM, BN, BK, WM, WN>;
+  auto kern = k_conv_gemm<BM, BN, BK, WM, WN, NSTAGE>;
   if (!attr_set) {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   T::LDS_BYTES));
     attr_set = true;
   }
   const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-  hipLaunchKernelGGL(kern, dim3(tiles, 1, p.nbatch), dim3(256), T::LDS_BYTES, st, p);
+  hipLaunchKernelGGL(kern, dim3(tiles, 1, p.nbatch), dim3(64 * T::NW), T::LDS_BYTES, st, p);
+}
+
+struct CfgInfo { int id, BM, BN, TN; const char* name; };
+// tile configurations (id = ConvGemmParams::tile); every id exists for BK=64 and BK=32
+const CfgInfo kCfgs[] = {
+    {1, 128, 128, 64, "128x128 w2x2 s2"},
+    {2, 128, 64, 64, "128x64 w4x1 s2"},
+    {3, 64, 64, 32, "64x64 w2x2 s2"},
+    {4, 128, 128, 64, "128x128 w2x2 s3"},
+    {5, 256, 128, 64, "256x128 w4x2 s3"},
+    {6, 128, 256, 64, "128x256 w2x4 s3"},
+    {7, 128, 64, 64, "128x64 w4x1 s4"},
+    {8, 64, 64, 32, "64x64 w2x2 s4"},
+    {9, 256, 64, 64, "256x64 w8x1 s4"},
+    {10, 128, 128, 64, "128x128 w2x2 s4"},
+    {11, 64, 128, 64, "64x128 w2x2 s4"},
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+template <int BK>
+void dispatch(hipStream_t st, const ConvGemmParams& p, int id) {
+  switch (id) {
+    case 1: launch_cfg<128, 128, BK, 2, 2, 2>(st, p); break;
+    case 2: launch_cfg<128, 64, BK, 4, 1, 2>(st, p); break;
+    case 3: launch_cfg<64, 64, BK, 2, 2, 2>(st, p); break;
+    case 4: launch_cfg<128, 128, BK, 2, 2, 3>(st, p); break;
+    case 5: launch_cfg<256, 128, BK, 4, 2, 3>(st, p); break;
+    case 6: launch_cfg<128, 256, BK, 2, 4, 3>(st, p); break;
+    case 7: launch_cfg<128, 64, BK, 4, 1, 4>(st, p); break;
+    case 8: launch_cfg<64, 64, BK, 2, 2, 4>(st, p); break;
+    case 9:
+      if constexpr (BK == 64) launch_cfg<256, 64, 64, 8, 1, 4>(st, p);
+      else launch_cfg<128, 64, 32, 4, 1, 4>(st, p);  // 8x1 waves need >= 8 glds rows groups per B tile
+      break;
+    case 10: launch_cfg<128, 128, BK, 2, 2, 4>(st, p); break;
+    case 11: launch_cfg<64, 128, BK, 2, 2, 4>(st, p); break;
+    default: CD_CHECK(false, "conv_gemm: unknown tile configuration %d", id);
+  }
 }
 
 thread_local const char* g_last_cfg = "";
 
-}  // namespace
+int pick_config(const ConvGemmParams& p) {
+  const int64_t t128 = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 128) * p.nbatch;
+  const int64_t t12864 = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 64) * p.nbatch;
+  if (p.act == ACT_GEGLU) return (t128 >= 384) ? 1 : 2;  // GEGLU needs a wave tile >= 64 columns wide
+  if (t128 >= 384 && p.N % 128 == 0) return 1;
+  if (t128 >= 512) return 1;
+  if (t12864 >= 256) return 2;
+  return 3;
+}
+
+}  // namespace gemm_detail
+using namespace gemm_detail;
 
 const char* conv_gemm_last_config() { return g_last_cfg; }
 
@@ -334,6 +468,59 @@ void KernelProfiler::collect(int* launches, double* total_ms, double* total_flop
 }
 KernelProfiler::~KernelProfiler() { for (auto e : events) (void)hipEventDestroy(e); }
 
+// ---- online autotuner: the engine replays the same few dozen contraction shapes hundreds of times, so
+// the first time a shape is seen every tile configuration is timed on it (HIP events, output redirected
+// to a scratch buffer so in-place residual updates are not disturbed) and the fastest is remembered.
+// Every configuration accumulates each output element in the same k order, so the choice never changes
+// a result bit.
+ConvTuner g_conv_tuner;
+
+namespace {
+struct ShapeKey {
+  int v[14];
+  bool operator<(const ShapeKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
+};
+std::map<ShapeKey, int>& tune_table() { static std::map<ShapeKey, int> t; return t; }
+
+int tuned_config(hipStream_t st, const ConvGemmParams& p, bool k64) {
+  ConvTuner& tu = g_conv_tuner;
+  if (!tu.enabled || !tu.scratch) return pick_config(p);
+  const int nout = (p.act == ACT_GEGLU) ? p.N / 2 : p.N;
+  const size_t need = (size_t)p.M * nout * 4 * p.nbatch;
+  if (need > tu.scratch_bytes) return pick_config(p);
+  ShapeKey key = {{p.M, p.N, p.Ktot, p.KH, p.C0, p.C1, p.stride, p.up, p.act, p.nbatch, p.out_f32, p.Hout, p.Wout,
+                   (p.resid ? 1 : 0) | (p.rowvec ? 2 : 0)}};
+  auto& tab = tune_table();
+  auto it = tab.find(key);
+  if (it != tab.end()) return it->second;
+  ConvGemmParams q = p;
+  q.out = tu.scratch; q.out_ld = nout; q.o_bs = (int64_t)p.M * nout;
+  if (p.resid && p.nbatch > 1) q.resid = nullptr;  // o_bs also strides the residual
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+  int best = pick_config(p);
+  float best_ms = 1e30f;
+  for (int i = 0; i < kNumCfgs; ++i) {
+    const CfgInfo& c = kCfgs[i];
+    if (p.act == ACT_GEGLU && c.TN < 64) continue;
+    if (c.BM >= 256 && p.M < 256) continue;
+    auto run = [&]() { if (k64) dispatch<64>(st, q, c.id); else dispatch<32>(st, q, c.id); };
+    run();  // warm
+    HIP_CHECK(hipEventRecord(e0, st));
+    run(); run();
+    HIP_CHECK(hipEventRecord(e1, st));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best_ms) { best_ms = ms; best = c.id; }
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  tab[key] = best;
+  ++tu.shapes_tuned;
+  return best;
+}
+}  // namespace
+
 void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   const int Ctot = p.C0 + p.C1;
   CD_CHECK(p.C0 % 32 == 0 && p.C1 % 32 == 0, "conv_gemm: channels must be multiples of 32 (C0=%d C1=%d)", p.C0, p.C1);
@@ -344,45 +531,34 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   CD_CHECK((p.ld0 % 8) == 0 && (p.src1 == nullptr || (p.ld1 % 8) == 0), "conv_gemm: ld must be a multiple of 8");
   if (p.act == ACT_GEGLU) CD_CHECK(p.N % 64 == 0, "GEGLU needs packed N %% 64 == 0");
   const bool k64 = (p.C0 % 64 == 0) && (p.C1 % 64 == 0);
-  // tile selection: fill >= ~1 wave of the 256 CUs when the problem allows it
-  int tile = p.tile;
-  if (tile == 0) {
-    const int64_t t128 = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 128) * p.nbatch;
-    const int64_t t12864 = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 64) * p.nbatch;
-    if (p.act == ACT_GEGLU) tile = (t128 >= 384) ? 1 : 2;  // GEGLU needs TN >= 64
-    else if (t128 >= 384 && p.N % 128 == 0) tile = 1;
-    else if (t128 >= 512) tile = 1;
-    else if (t12864 >= 256) tile = 2;
-    else tile = 3;
-  }
-  if (p.act == ACT_GEGLU && tile == 3) tile = 2;
+  int id = p.tile ? p.tile : tuned_config(st, p, k64);
+  const CfgInfo* ci = nullptr;
+  for (int i = 0; i < kNumCfgs; ++i) if (kCfgs[i].id == id) ci = &kCfgs[i];
+  CD_CHECK(ci, "conv_gemm: unknown tile configuration %d", id);
+  if (p.act == ACT_GEGLU && ci->TN < 64) { id = 2; ci = &kCfgs[1]; }
+  g_last_cfg = ci->name;
   KernelProfiler* prof = g_conv_prof;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (prof && prof->enabled) {
     prof->next_pair(&e0, &e1, 2.0 * (double)p.M * (double)p.N * (double)p.Ktot * (double)p.nbatch);
     (void)hipEventRecord(e0, st);
   }
-  struct Closer {  // record the stop event on every exit path of the switch below
+  struct Closer {  // record the stop event on every exit path
     hipEvent_t e; hipStream_t s;
     ~Closer() { if (e) (void)hipEventRecord(e, s); }
   } closer{e1, st};
-  if (k64) {
-    switch (tile) {
-      case 1: g_last_cfg = "128x128x64"; launch_cfg<128, 128, 64, 2, 2>(st, p); break;
-      case 2: g_last_cfg = "128x64x64"; launch_cfg<128, 64, 64, 4, 1>(st, p); break;
-      default: g_last_cfg = "64x64x64"; launch_cfg<64, 64, 64, 2, 2>(st, p); break;
-    }
-  } else {
-    switch (tile) {
-      case 1: g_last_cfg = "128x128x32"; launch_cfg<128, 128, 32, 2, 2>(st, p); break;
-      case 2: g_last_cfg = "128x64x32"; launch_cfg<128, 64, 32, 4, 1>(st, p); break;
-      default: g_last_cfg = "64x64x32"; launch_cfg<64, 64, 32, 2, 2>(st, p); break;
-    }
-  }
+  if (k64) dispatch<64>(st, p, id);
+  else dispatch<32>(st, p, id);
+}
+
+int conv_gemm_num_configs() { return kNumCfgs; }
+const char* conv_gemm_config_name(int id) {
+  for (int i = 0; i < kNumCfgs; ++i) if (kCfgs[i].id == id) return kCfgs[i].name;
+  return "?";
 }
 
 // ------------------------------------------------------------------------------------------------
-// Weight repack: torch fp32 [N][Cin][KH][KW] -> bf16 [Npad][KH][KW][Cpad], zero padded.
+// Weight repack: torch fp32 [N][Cin][KH][KW] -> 16-bit [Npad][KH][KW][Cpad], zero padded.
 // geglu=1: source rows are [value(N/2) | gate(N/2)] (GEGLU.proj, attention.py:37-44); packed rows
 // are interleaved in blocks of 32 so value n and gate n sit 32 columns apart in one wave tile.
 __global__ void k_repack_weight(const float* __restrict__ w, bf16_t* __restrict__ out, int N, int Cin,

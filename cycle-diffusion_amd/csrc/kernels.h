@@ -77,6 +77,8 @@ struct ConvGemmParams {
 };
 void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p);
 const char* conv_gemm_last_config();
+int conv_gemm_num_configs();
+const char* conv_gemm_config_name(int id);
 
 // Optional per-launch timing of the dominant kernel family with HIP events recorded on the launch
 // stream (bench.py's roofline leg). flops = 2*M*N*K per launch (algorithmic, padding excluded except
@@ -91,6 +93,15 @@ struct KernelProfiler {
   ~KernelProfiler();
 };
 extern KernelProfiler* g_conv_prof;
+
+// online tile-configuration autotuner of the implicit-GEMM kernel (conv_gemm.hip)
+struct ConvTuner {
+  bool enabled = false;
+  void* scratch = nullptr;   // device scratch for redirected outputs while timing
+  size_t scratch_bytes = 0;
+  int shapes_tuned = 0;
+};
+extern ConvTuner g_conv_tuner;
 
 // weight repack: fp32 [N][Cin][KH][KW] (torch conv / linear with KH=KW=1) -> bf16 [Npad][KH*KW*Cpad]
 // with zero padding; `geglu` interleaves value/gate rows in blocks of 32 (see conv_gemm.hip).

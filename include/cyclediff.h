@@ -146,7 +146,10 @@ int cd_op_timestep_embedding(cd_handle h, const float* t, int B, int dim, int mo
 int cd_op_sched_step(cd_handle h, int mode, int sched_kind, const cd_step_coef* coef_host, const float* x0,
                      float* xt, const float* eps_hat, int cfg, float guidance, const float* noise,
                      const float* eps_in, int is_last, int B, int C, int HW, float* z_slot);
-/* raw MFMA / LDS layout probe used by tests/test_gpu_probe.py */
+/* micro-benchmark of one conv / GEMM shape on synthetic data (scripts/bench_gemm.py): average ms per launch */
+int cd_op_bench_conv(cd_handle h, int B, int H, int W, int C0, int C1, int N, int k, int stride, int up,
+                     int act, int tile, int iters, float* ms_out);
+/* raw MFMA / LDS layout probe used by tests/test_gpu_ops.py */
 int cd_op_probe(cd_handle h, int which, const void* in, void* out, size_t n);
 
 #ifdef __cplusplus
