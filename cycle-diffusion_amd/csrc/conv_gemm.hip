@@ -298,11 +298,16 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
     bias_v[e] = (p.bias && e < nvalid) ? p.bias[n + e] : 0.0f;
     bias_g[e] = (geglu && p.bias) ? p.bias[n + 32 + e] : 0.0f;
   }
+  // optional fused GroupNorm statistics: per-channel sum / sum-of-squares of the FINAL values over each
+  // 32-row block of the output, written to stats[rowblock][2][N] (no atomics; the 32-row granularity is
+  // independent of the tile configuration and of the batch size)
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
   for (int r0 = 0; r0 < TM; r0 += rpp) {
     const int row = r0 + vr;
-    if (row >= TM) continue;
     const int m = m0 + wm * TM + row;
-    if (m >= p.M || n >= p.N) continue;
+    if (row < TM && m < p.M && n < p.N) {
     float v[8];
     {
       const f32x4 lo = *(const f32x4*)(E + row * T::EPI_LD + col);
@@ -369,6 +374,26 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) if (e < nvalid) op[e] = f2bf(v[e]);
       }
+    }
+    if (p.stats) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+    }
+    }  // valid row
+    if (p.stats && ((r0 + rpp) & 31) == 0) {
+      // end of a 32-row block: fold the lanes that share this column vector (same vc, different vr)
+      for (int o = vpr; o < 64; o <<= 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ssum[e] += __shfl_xor(ssum[e], o); ssq[e] += __shfl_xor(ssq[e], o); }
+      }
+      const int rb = (m0 + wm * TM + r0 + rpp - 32) >> 5;
+      if (vr == 0 && n < p.N && (rb << 5) < p.M) {
+        float* sp = p.stats + ((int64_t)zb * ((p.M + 31) >> 5) + rb) * 2 * p.N + n;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (e < nvalid) { sp[e] = ssum[e]; sp[p.N + e] = ssq[e]; }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
     }
   }
 #endif  // __HIP_DEVICE_COMPILE__

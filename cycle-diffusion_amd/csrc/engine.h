@@ -35,6 +35,10 @@ struct Act {  // NHWC bf16 activation view
   bf16_t* p = nullptr;
   int B = 0, H = 0, W = 0, C = 0;
   int ld = 0;  // pixel stride (elements)
+  // GroupNorm statistics of this tensor, written by the conv epilogue that produced it
+  // ([B*H*W/32][2][C] fp32, ConvGemmParams::stats); stats_buf = storage, stats = valid content
+  float* stats = nullptr;
+  float* stats_buf = nullptr;
   int64_t rows() const { return (int64_t)B * H * W; }
 };
 
@@ -122,9 +126,11 @@ struct ConvOpts {
   bool out_f32 = false;
   void* out = nullptr;  // optional preallocated output
   int out_ld = 0;
+  bool want_stats = false;     // output feeds a GroupNorm: emit its statistics from the epilogue
+  float* out_stats = nullptr;  // storage for them when `out` is preallocated
   int tile = 0;
 };
-Act alloc_act(Ctx& c, int B, int H, int W, int C);
+Act alloc_act(Ctx& c, int B, int H, int W, int C, bool with_stats = false);
 // y = conv(x [| x2]) with the fused epilogue; returns the output view (bf16 unless out_f32)
 Act conv_fwd(Ctx& c, const ConvW& w, const Act& x, const Act* x2, const ConvOpts& o);
 

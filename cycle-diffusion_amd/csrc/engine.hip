@@ -192,9 +192,11 @@ int ParamStore::missing(std::string* first) const {
 }
 
 // ------------------------------------------------------------------ building blocks
-Act alloc_act(Ctx& c, int B, int H, int W, int C) {
+Act alloc_act(Ctx& c, int B, int H, int W, int C, bool with_stats) {
   Act a; a.B = B; a.H = H; a.W = W; a.C = C; a.ld = C;
   a.p = (bf16_t*)c.arena->alloc((size_t)B * H * W * C * sizeof(bf16_t));
+  if (with_stats && ((H * W) % 32) == 0)
+    a.stats_buf = (float*)c.arena->alloc((size_t)(B * H * W / 32) * 2 * C * sizeof(float));
   return a;
 }
 
@@ -235,6 +237,13 @@ Act conv_fwd(Ctx& c, const ConvW& w, const Act& x, const Act* x2, const ConvOpts
   }
   p.out = y.p; p.out_ld = y.ld; p.out_f32 = o.out_f32 ? 1 : 0;
   p.zeros = c.zeros; p.tile = o.tile;
+  if (!w.geglu && !o.out_f32 && ((p.Hout * p.Wout) % 32) == 0) {
+    if (o.out && o.out_stats) y.stats_buf = o.out_stats;
+    else if (!o.out && o.want_stats)
+      y.stats_buf = (float*)c.arena->alloc((size_t)(p.M / 32) * 2 * Nout * sizeof(float));
+    p.stats = y.stats_buf;
+    y.stats = y.stats_buf;
+  }
   launch_conv_gemm(c.st, p);
   return y;
 }
@@ -253,6 +262,10 @@ Act groupnorm_fwd(Ctx& c, const GNW& w, const Act& x, const Act* x2, bool silu, 
   p.S = groupnorm_slabs(p.B, p.HW, C);
   CD_CHECK((size_t)p.B * p.S * p.G * 2 <= c.gn_partial_floats, "groupnorm: partial workspace too small");
   p.partial = c.gn_partial;
+  if (x.stats && x.ld == x.C && (!x2 || (x2->stats && x2->ld == x2->C))) {
+    p.pre0 = x.stats;
+    p.pre1 = x2 ? x2->stats : nullptr;
+  }
   launch_groupnorm(c.st, p);
   return y;
 }

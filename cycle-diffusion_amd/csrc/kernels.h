@@ -72,6 +72,9 @@ struct ConvGemmParams {
   void* out = nullptr;
   int out_ld = 0;
   int out_f32 = 0;
+  // optional fused GroupNorm statistics of the output: [nbatch][ceil(M/32)][2][N] fp32 (sum | sum of squares
+  // per channel over each 32-row block); null = off. Not available with GEGLU.
+  float* stats = nullptr;
   const bf16_t* zeros = nullptr;  // >= 256 B of zeros (masked rows / padding taps)
   int tile = 0;                   // 0 = auto
 };
@@ -124,6 +127,10 @@ struct GroupNormParams {
   bf16_t* y = nullptr;          // [B][HW][C] dense
   float* partial = nullptr;     // workspace [B][S][G][2]
   int S = 0;
+  // statistics already produced by the conv epilogue that wrote x / x1 (ConvGemmParams::stats layout,
+  // [B*HW/32][2][C]): when set, the stats pass is replaced by a small per-(image, group) fold
+  const float* pre0 = nullptr;
+  const float* pre1 = nullptr;
 };
 int groupnorm_slabs(int B, int HW, int C);
 void launch_groupnorm(hipStream_t st, const GroupNormParams& p);

@@ -67,10 +67,10 @@ AtW mk_at(ParamStore& ps, const std::string& pfx, int C) {
 }
 
 Act rn_fwd(Ctx& c, const RnW& r, const Act& x, const Act* x2, const float* proj, int proj_ld, bool t_shared) {
-  Act out = alloc_act(c, x.B, x.H, x.W, r.cout);
+  Act out = alloc_act(c, x.B, x.H, x.W, r.cout, /*with_stats=*/true);
   const size_t mk = c.arena->mark();
   Act h = groupnorm_fwd(c, r.n1, x, x2, true);
-  ConvOpts o1;
+  ConvOpts o1; o1.want_stats = true;
   if (r.emb_off >= 0) {
     o1.rowvec = proj + r.emb_off; o1.rowvec_ld = proj_ld;
     o1.rows_per_vec = t_shared ? INT_MAX : x.H * x.W;
@@ -80,8 +80,9 @@ Act rn_fwd(Ctx& c, const RnW& r, const Act& x, const Act* x2, const float* proj,
   Act skip;
   if (r.nin) { ConvOpts os; os.pad = 0; skip = conv_fwd(c, *r.nin, x, x2, os); }
   else { CD_CHECK(!x2, "identity shortcut with concat input"); skip = x; }
-  ConvOpts o2; o2.resid = &skip; o2.out = out.p; o2.out_ld = out.ld;
+  ConvOpts o2; o2.resid = &skip; o2.out = out.p; o2.out_ld = out.ld; o2.out_stats = out.stats_buf;
   conv_fwd(c, *r.c2, h3, nullptr, o2);
+  out.stats = out.stats_buf;
   c.arena->release(mk);
   return out;
 }
@@ -99,7 +100,7 @@ void vt_gemm2(Ctx& c, const ConvW& wv, const bf16_t* x, int ldx, int B, int T, i
 
 Act at_fwd(Ctx& c, const AtW& a, const Act& x) {
   const int B = x.B, T = x.H * x.W, C = a.C;
-  Act out = alloc_act(c, B, x.H, x.W, C);
+  Act out = alloc_act(c, B, x.H, x.W, C, /*with_stats=*/true);
   const size_t mk = c.arena->mark();
   ConvOpts p0; p0.pad = 0;
   Act n = groupnorm_fwd(c, a.norm, x, nullptr, false);
@@ -140,8 +141,9 @@ Act at_fwd(Ctx& c, const AtW& a, const Act& x) {
     h.bias = a.vbias; h.out = o.p; h.out_ld = o.ld; h.zeros = c.zeros;
     launch_conv_gemm(c.st, h);
   }
-  ConvOpts po; po.pad = 0; po.resid = &x; po.out = out.p; po.out_ld = out.ld;
+  ConvOpts po; po.pad = 0; po.resid = &x; po.out = out.p; po.out_ld = out.ld; po.out_stats = out.stats_buf;
   conv_fwd(c, *a.proj, o, nullptr, po);
+  out.stats = out.stats_buf;
   c.arena->release(mk);
   return out;
 }
@@ -214,11 +216,11 @@ VAEKL::VAEKL(const cd_net_desc& d) {
 void VAEKL::encode_moments(Ctx& c, const bf16_t* img, int B, int R, float* moments) {
   const size_t mk = c.arena->mark();
   Act x; x.p = (bf16_t*)img; x.B = B; x.H = R; x.W = R; x.C = round_up(in_ch_, 32); x.ld = x.C;
-  ConvOpts o3;
+  ConvOpts o3; o3.want_stats = true;
   Act h = conv_fwd(c, *e_in_, x, nullptr, o3);
   for (int l = 0; l < nlev_; ++l) {
     for (auto& r : e_blk_[l]) h = rn_fwd(c, r, h, nullptr, nullptr, 0, true);
-    if (e_down_[l]) { ConvOpts od; od.stride = 2; od.asym = true; h = conv_fwd(c, *e_down_[l], h, nullptr, od); }
+    if (e_down_[l]) { ConvOpts od; od.stride = 2; od.asym = true; od.want_stats = true; h = conv_fwd(c, *e_down_[l], h, nullptr, od); }
   }
   h = rn_fwd(c, e_m1_, h, nullptr, nullptr, 0, true);
   h = at_fwd(c, e_at_, h);
@@ -243,14 +245,14 @@ void VAEKL::decode(Ctx& c, const bf16_t* z, int B, int hl, float* img) {
   HIP_CHECK(hipMemsetAsync(zq.p, 0, (size_t)zq.rows() * cp * 2, c.st));
   ConvOpts oq; oq.pad = 0; oq.out = zq.p; oq.out_ld = cp;
   conv_fwd(c, *pq_, x, nullptr, oq);
-  ConvOpts o3;
+  ConvOpts o3; o3.want_stats = true;
   Act h = conv_fwd(c, *d_in_, zq, nullptr, o3);
   h = rn_fwd(c, d_m1_, h, nullptr, nullptr, 0, true);
   h = at_fwd(c, d_at_, h);
   h = rn_fwd(c, d_m2_, h, nullptr, nullptr, 0, true);
   for (int l = nlev_ - 1; l >= 0; --l) {
     for (auto& r : d_blk_[l]) h = rn_fwd(c, r, h, nullptr, nullptr, 0, true);
-    if (d_up_[l]) { ConvOpts ou; ou.up = true; h = conv_fwd(c, *d_up_[l], h, nullptr, ou); }
+    if (d_up_[l]) { ConvOpts ou; ou.up = true; ou.want_stats = true; h = conv_fwd(c, *d_up_[l], h, nullptr, ou); }
   }
   Act n = groupnorm_fwd(c, d_no_, h, nullptr, true);
   ConvOpts oo; oo.out_f32 = true; oo.out = img; oo.out_ld = out_ch_;
@@ -366,7 +368,7 @@ void UNetHo::forward(Ctx& c, const UNetIO& io) {
                     te_.proj_total, 1, 0);
   const int pl = te_.proj_total;
   Act x; x.p = (bf16_t*)io.xin; x.B = B; x.H = R; x.W = R; x.C = in_cpad; x.ld = in_cpad;
-  ConvOpts o3;
+  ConvOpts o3; o3.want_stats = true;
   std::vector<Act> hs;
   hs.push_back(conv_fwd(c, *cin_, x, nullptr, o3));
   for (int l = 0; l < nlev_; ++l) {
@@ -376,7 +378,7 @@ void UNetHo::forward(Ctx& c, const UNetIO& io) {
       hs.push_back(h);
     }
     if (down_[l].resamp) {
-      ConvOpts od; od.stride = 2; od.asym = true;
+      ConvOpts od; od.stride = 2; od.asym = true; od.want_stats = true;
       hs.push_back(conv_fwd(c, *down_[l].resamp, hs.back(), nullptr, od));
     }
   }
@@ -390,7 +392,7 @@ void UNetHo::forward(Ctx& c, const UNetIO& io) {
       h = rn_fwd(c, up_[l].blk[b], h, &skip, proj, pl, io.t_shared);
       if (!up_[l].att.empty()) h = at_fwd(c, up_[l].att[b], h);
     }
-    if (up_[l].resamp) { ConvOpts ou; ou.up = true; h = conv_fwd(c, *up_[l].resamp, h, nullptr, ou); }
+    if (up_[l].resamp) { ConvOpts ou; ou.up = true; ou.want_stats = true; h = conv_fwd(c, *up_[l].resamp, h, nullptr, ou); }
   }
   Act n = groupnorm_fwd(c, no_, h, nullptr, true);
   ConvOpts oo; oo.out_f32 = true; oo.out = io.out; oo.out_ld = io.out_ld;

@@ -94,6 +94,39 @@ __global__ __launch_bounds__(256) void k_gn_stats(GroupNormParams p, int rows_pe
   }
 }
 
+// grid (G, B): fold the per-32-row-block channel sums written by the producing conv's epilogue
+// (ConvGemmParams::stats) into one (sum, sumsq) per image and group -> partial[b][0][g][2] (S = 1).
+__global__ __launch_bounds__(256) void k_gn_fold(GroupNormParams p) {
+  __shared__ float rs[256], rq[256];
+  const int C = p.C0 + p.C1;
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / p.G;
+  const int nb = p.HW >> 5;
+  const int items = nb * cpg;
+  float a = 0.f, q = 0.f;
+  for (int it = tid; it < items; it += 256) {
+    const int rb = it / cpg, c = g * cpg + (it - rb * cpg);
+    const int64_t blk = (int64_t)b * nb + rb;
+    if (c < p.C0) {
+      const float* s = p.pre0 + blk * 2 * p.C0 + c;
+      a += s[0]; q += s[p.C0];
+    } else {
+      const float* s = p.pre1 + blk * 2 * p.C1 + (c - p.C0);
+      a += s[0]; q += s[p.C1];
+    }
+  }
+  rs[tid] = a; rq[tid] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {  // fixed-order tree: deterministic
+    if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float* o = p.partial + ((int64_t)b * p.G + g) * 2;
+    o[0] = rs[0]; o[1] = rq[0];
+  }
+}
+
 // grid (row_chunks, B): y = (x-mean)*rstd*gamma+beta [FiLM] [SiLU]
 __global__ __launch_bounds__(256) void k_gn_apply(GroupNormParams p, int rows_per_block) {
   __shared__ float s_mean[64], s_rstd[64];
@@ -261,13 +294,19 @@ void launch_groupnorm(hipStream_t st, const GroupNormParams& p) {
   CD_CHECK(p.partial && p.S > 0, "groupnorm: workspace missing");
   const int nvec = C >> 3;
   const int rif = nvec <= 256 ? 256 / nvec : 1;
-  const int rows_per_slab = ceil_div(p.HW, p.S);
-  const size_t lds = (size_t)rif * C * 2 * sizeof(float);
-  hipLaunchKernelGGL(k_gn_stats, dim3(p.S, p.B), dim3(256), lds, st, p, rows_per_slab);
-  int rows_per_block = 32768 / C;  // ~64 KB of bf16 per block
+  GroupNormParams q = p;
+  if (p.pre0 && (p.C1 == 0 || p.pre1) && (p.HW % 32) == 0) {
+    q.S = 1;  // statistics came out of the producing convs' epilogues: fold them per (image, group)
+    hipLaunchKernelGGL(k_gn_fold, dim3(p.G, p.B), dim3(256), 0, st, q);
+  } else {
+    const int rows_per_slab = ceil_div(p.HW, p.S);
+    const size_t lds = (size_t)rif * C * 2 * sizeof(float);
+    hipLaunchKernelGGL(k_gn_stats, dim3(p.S, p.B), dim3(256), lds, st, p, rows_per_slab);
+  }
+  int rows_per_block = 32768 / C;  // ~64 KB of 16-bit data per block
   if (rows_per_block < 1) rows_per_block = 1;
   hipLaunchKernelGGL(k_gn_apply, dim3(ceil_div(p.HW, rows_per_block), p.B), dim3(256),
-                     (size_t)C * 2 * sizeof(float), st, p, rows_per_block);
+                     (size_t)C * 2 * sizeof(float), st, q, rows_per_block);
 }
 
 void launch_layernorm(hipStream_t st, const bf16_t* x, int ldx, bf16_t* y, int ldy, int rows,

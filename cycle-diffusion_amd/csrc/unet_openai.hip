@@ -286,7 +286,7 @@ Act UNetOpenAI::res_fwd(Ctx& c, const ResW& r, const Act& x, const Act* x2, cons
   // output first (it outlives the block's temporaries)
   const int Ho = r.up ? x.H * 2 : (r.down ? x.H / 2 : x.H);
   const int Wo = r.up ? x.W * 2 : (r.down ? x.W / 2 : x.W);
-  Act out = alloc_act(c, x.B, Ho, Wo, r.cout);
+  Act out = alloc_act(c, x.B, Ho, Wo, r.cout, /*with_stats=*/true);
   const int rpv = t_shared ? INT_MAX : Ho * Wo;  // output rows sharing one time-embedding vector
   const size_t mk = c.arena->mark();
   Act h = groupnorm_fwd(c, r.gn1, x, x2, /*silu=*/true);
@@ -308,7 +308,7 @@ Act UNetOpenAI::res_fwd(Ctx& c, const ResW& r, const Act& x, const Act* x2, cons
     launch_upsample2(c.st, x.p, xu.p, x.B, x.H, x.W, r.cin);
     xs = xu; xs2 = nullptr;
   }
-  ConvOpts o1; o1.up = up_in_conv;
+  ConvOpts o1; o1.up = up_in_conv; o1.want_stats = true;
   const float* pr = proj + r.emb_off;
   if (!r.film) { o1.rowvec = pr; o1.rowvec_ld = proj_ld; o1.rows_per_vec = rpv; }
   Act h2 = conv_fwd(c, *r.conv1, h, nullptr, o1);
@@ -323,8 +323,9 @@ Act UNetOpenAI::res_fwd(Ctx& c, const ResW& r, const Act& x, const Act* x2, cons
     CD_CHECK(!xs2, "identity skip with concat input");
     skip = xs;
   }
-  ConvOpts o2; o2.resid = &skip; o2.out = out.p; o2.out_ld = out.ld;
+  ConvOpts o2; o2.resid = &skip; o2.out = out.p; o2.out_ld = out.ld; o2.out_stats = out.stats_buf;
   conv_fwd(c, *r.conv2, h3, nullptr, o2);
+  out.stats = out.stats_buf;
   c.arena->release(mk);
   return out;
 }
@@ -366,7 +367,7 @@ void UNetOpenAI::set_context(Ctx& c, const bf16_t* ctx, int B, int L) {
 
 Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x) {
   const int B = x.B, T = x.H * x.W, C = s.C;
-  Act out = alloc_act(c, B, x.H, x.W, C);
+  Act out = alloc_act(c, B, x.H, x.W, C, /*with_stats=*/true);
   const size_t mk = c.arena->mark();
   CD_CHECK(s.k2c && ctx_B_ == B, "cross-attention context not set for batch %d", B);
   ConvOpts p0; p0.pad = 0;
@@ -403,15 +404,16 @@ Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x) {
     conv_fwd(c, *s.ff2, g, nullptr, o);
     c.arena->release(m2);
   }
-  ConvOpts po; po.pad = 0; po.resid = &x; po.out = out.p; po.out_ld = out.ld;
+  ConvOpts po; po.pad = 0; po.resid = &x; po.out = out.p; po.out_ld = out.ld; po.out_stats = out.stats_buf;
   conv_fwd(c, *s.proj_out, h, nullptr, po);
+  out.stats = out.stats_buf;
   c.arena->release(mk);
   return out;
 }
 
 Act UNetOpenAI::ab_fwd(Ctx& c, const ABW& a, const Act& x) {
   const int B = x.B, T = x.H * x.W, C = a.C;
-  Act out = alloc_act(c, B, x.H, x.W, C);
+  Act out = alloc_act(c, B, x.H, x.W, C, /*with_stats=*/true);
   const size_t mk = c.arena->mark();
   ConvOpts p0; p0.pad = 0;
   Act n = groupnorm_fwd(c, a.norm, x, nullptr, false);
@@ -428,8 +430,9 @@ Act UNetOpenAI::ab_fwd(Ctx& c, const ABW& a, const Act& x) {
   p.q_bs = (int64_t)T * qk.ld; p.k_bs = (int64_t)T * qk.ld; p.o_bs = (int64_t)T * o.ld;
   p.vt_dpad = a.dh; p.vt_tpad = Tpad; p.scale = 1.0f / sqrtf((float)a.dh); p.obias = a.vbias;
   launch_attention(c.st, p);
-  ConvOpts po; po.pad = 0; po.resid = &x; po.out = out.p; po.out_ld = out.ld;
+  ConvOpts po; po.pad = 0; po.resid = &x; po.out = out.p; po.out_ld = out.ld; po.out_stats = out.stats_buf;
   conv_fwd(c, *a.proj, o, nullptr, po);
+  out.stats = out.stats_buf;
   c.arena->release(mk);
   return out;
 }
@@ -440,12 +443,12 @@ Act UNetOpenAI::run_block(Ctx& c, const Block& b, Act h, const Act* skip, const 
   for (const Layer& l : b.layers) {
     const Act* x2 = first ? skip : nullptr;
     switch (l.kind) {
-      case Layer::CONV_IN: { ConvOpts o; h = conv_fwd(c, *l.conv, h, nullptr, o); break; }
+      case Layer::CONV_IN: { ConvOpts o; o.want_stats = true; h = conv_fwd(c, *l.conv, h, nullptr, o); break; }
       case Layer::RES: h = res_fwd(c, res_[l.idx], h, x2, proj, proj_ld, t_shared); break;
       case Layer::ST: h = st_fwd(c, st_[l.idx], h); break;
       case Layer::AB: h = ab_fwd(c, ab_[l.idx], h); break;
-      case Layer::DOWN_CONV: { ConvOpts o; o.stride = 2; h = conv_fwd(c, *l.conv, h, nullptr, o); break; }
-      case Layer::UP_CONV: { ConvOpts o; o.up = true; h = conv_fwd(c, *l.conv, h, nullptr, o); break; }
+      case Layer::DOWN_CONV: { ConvOpts o; o.stride = 2; o.want_stats = true; h = conv_fwd(c, *l.conv, h, nullptr, o); break; }
+      case Layer::UP_CONV: { ConvOpts o; o.up = true; o.want_stats = true; h = conv_fwd(c, *l.conv, h, nullptr, o); break; }
     }
     first = false;
   }
