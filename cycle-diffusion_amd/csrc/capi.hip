@@ -81,6 +81,14 @@ int cd_engine_create(void* hip_stream, size_t workspace_bytes, cd_handle* out) {
       g_conv_tuner.enabled = true;
     }
   }
+  if (!g_conv_splitk.scratch) {  // split-K partial tiles + arrival counters (conv_gemm.hip)
+    g_conv_splitk.scratch_bytes = (size_t)256 << 20;
+    g_conv_splitk.nflags = 1 << 16;
+    HIP_CHECK(hipMalloc((void**)&g_conv_splitk.scratch, g_conv_splitk.scratch_bytes));
+    HIP_CHECK(hipMalloc((void**)&g_conv_splitk.flags, g_conv_splitk.nflags * sizeof(int)));
+    HIP_CHECK(hipMemset(g_conv_splitk.flags, 0, g_conv_splitk.nflags * sizeof(int)));
+    HIP_CHECK(hipDeviceSynchronize());
+  }
   h->gn_partial_floats = (size_t)1 << 20;
   HIP_CHECK(hipMalloc((void**)&h->gn_partial, h->gn_partial_floats * sizeof(float)));
   *out = h.release();
@@ -104,6 +112,10 @@ int cd_prof_enable(cd_handle h, int on) {
   CD_CHECK(h, "null handle");
   if (!h->prof) h->prof.reset(new KernelProfiler());
   h->prof->enabled = on != 0;
+  {
+    const char* e = getenv("CYCLEDIFF_GEMM_LOG");
+    h->prof->verbose = e && e[0] == '1';
+  }
   g_conv_prof = on ? h->prof.get() : nullptr;
   CD_API_END
 }

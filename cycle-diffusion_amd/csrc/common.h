@@ -78,6 +78,21 @@ __device__ inline void unpack8(const uint4& raw, float* f) {
 __device__ inline uint32_t pack2(float lo, float hi) {
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
+// two values known to lie in [0, 1] (softmax probabilities): no saturation needed
+__device__ inline uint32_t pack2_unit(float lo, float hi) {
+#if CD_ACT_FP16
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  const h2 v = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+#else
+  return pack2(lo, hi);
+#endif
+}
+#if CD_ACT_FP16
+constexpr uint32_t kOnePair = 0x3C003C00u;  // two 16-bit 1.0 values
+#else
+constexpr uint32_t kOnePair = 0x3F803F80u;
+#endif
 __device__ inline uint4 pack8(const float* f) {
   uint4 r;
   r.x = pack2(f[0], f[1]); r.y = pack2(f[2], f[3]);

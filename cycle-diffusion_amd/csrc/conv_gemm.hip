@@ -17,7 +17,9 @@
 // depend on which configuration (or batch size) is chosen.
 #include <string.h>
 
+#include <algorithm>
 #include <map>
+#include <string>
 
 #include "common.h"
 #include "kernels.h"
@@ -149,8 +151,21 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
 
   const int Ctot = p.C0 + p.C1;
   const int nk = p.Ktot / BK;
+  // split-K: blockIdx.y owns the K steps [kt0, kt1); partial tiles meet in the fix-up before the epilogue
+  const int nsplit = gridDim.y, sidx = blockIdx.y;
+  const int kper = (nk + nsplit - 1) / nsplit;
+  const int kt0 = sidx * kper;
+  const int kt1 = (kt0 + kper < nk) ? kt0 + kper : nk;
   // K-step cursor (uniform): tap (kr, kss) and channel offset kc within the concatenated channels
-  int kr = 0, kss = 0, kc = 0;
+  int kr, kss, kc;
+  {
+    const int k_el = kt0 * BK;
+    const int tap = k_el / Ctot;
+    kc = k_el - tap * Ctot;
+    kr = tap / p.KW;
+    kss = tap - kr * p.KW;
+  }
+  bool st_force = true;  // the first live tile of a split may start in the middle of a tap
 
   char* As = smem;                       // [NSTAGE][BM*BK*2]
   char* Bs = smem + NSTAGE * T::A_BYTES; // [NSTAGE][BN*BK*2]
@@ -163,14 +178,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
   int st_soffa = 0, st_soffb = 0;
   const bf16_t* st_base = base0;
   auto prepare = [&](int kt) {
-    st_live = kt < nk;
+    st_live = kt < kt1;
     const int c_kc = kc, c_kr = kr, c_kss = kss;
     kc += BK;
     if (kc >= Ctot) {
       kc = 0;
       if (++kss >= p.KW) { kss = 0; ++kr; }
     }
-    if (st_live && (c_kc == 0 || c_kc == p.C0)) {  // new filter tap / second concat source
+    if (st_live && (c_kc == 0 || c_kc == p.C0 || st_force)) {  // new filter tap / second concat source
+      st_force = false;
       const int ld = (c_kc < p.C0) ? p.ld0 : p.ld1;
 #pragma unroll
       for (int i = 0; i < A_IPW; ++i) {
@@ -214,14 +230,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
   // ---- prologue: fill NSTAGE-1 ring slots
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s) {
-    prepare(s);
+    prepare(kt0 + s);
 #pragma unroll
     for (int l = 0; l < LPT; ++l) issue(l, s);
   }
 
   int cur = 0;             // ring slot of tile kt
   int nxt = NSTAGE - 1;    // ring slot the next prefetch goes to (= slot of tile kt-1)
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt0; kt < kt1; ++kt) {
     // tile kt has landed when at most (NSTAGE-2) younger tiles (LPT loads each) are still in flight
     wait_vmcnt_barrier<(NSTAGE - 2) * LPT>();
     // every wave has passed the barrier => everyone finished reading slot `nxt` (tile kt-1): refill it
@@ -265,6 +281,47 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy tail loads before LDS is reused
   __syncthreads();  // all waves done with the ring before the epilogue reuses LDS
+
+  // ---- split-K fix-up: every split stores its fp32 partial tile (register layout, coalesced), the last
+  // one to arrive sums all partials in split order (so the result does not depend on arrival order) and
+  // runs the epilogue; the tile's arrival counter is reset for the next launch.
+  if (nsplit > 1) {
+    constexpr int TILE_ELEMS = BM * BN;
+    float* part0 = p.sk_scratch + ((int64_t)zb * ntiles + tile) * nsplit * TILE_ELEMS;
+    float* mine = part0 + (int64_t)sidx * TILE_ELEMS + tid;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[((i * NT + j) * 16 + r) * (64 * NW)] = acc[i][j][r];
+    __threadfence();
+    __syncthreads();
+    int* flag = p.sk_flags + zb * ntiles + tile;
+    if (tid == 0) *(volatile int*)smem = atomicAdd(flag, 1);
+    __syncthreads();
+    const int arrived = *(volatile int*)smem;
+    __syncthreads();
+    if (arrived != nsplit - 1) return;
+    __threadfence();
+    if (tid == 0) *flag = 0;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+      const float* src = part0 + (int64_t)sp * TILE_ELEMS + tid;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            acc[i][j][r] += __builtin_nontemporal_load(src + ((i * NT + j) * 16 + r) * (64 * NW));
+    }
+  }
 
   // ---- epilogue: accumulators -> LDS (fp32, per-wave region) -> fused elementwise -> 16-B stores
   float* E = (float*)smem + wave * (TM * T::EPI_LD);
@@ -410,7 +467,14 @@ void launch_cfg(hipStream_t st, const ConvGemmParams& p) {
     attr_set = true;
   }
   const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-  hipLaunchKernelGGL(kern, dim3(tiles, 1, p.nbatch), dim3(64 * T::NW), T::LDS_BYTES, st, p);
+  const int split = p.splitk > 1 ? p.splitk : 1;
+  if (split > 1) {
+    const SplitKWorkspace& ws = g_conv_splitk;
+    CD_CHECK(p.sk_scratch && p.sk_flags, "conv_gemm: split-K without workspace");
+    CD_CHECK((size_t)tiles * p.nbatch * split * BM * BN * 4 <= ws.scratch_bytes && tiles * p.nbatch <= ws.nflags,
+             "conv_gemm: split-K workspace too small");
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles, split, p.nbatch), dim3(64 * T::NW), T::LDS_BYTES, st, p);
 }
 
 struct CfgInfo { int id, BM, BN, TN; const char* name; };
@@ -429,6 +493,10 @@ const CfgInfo kCfgs[] = {
     {11, 64, 128, 64, "64x128 w2x2 s4"},
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+}  // namespace gemm_detail
+SplitKWorkspace g_conv_splitk;
+namespace gemm_detail {
 
 template <int BK>
 void dispatch(hipStream_t st, const ConvGemmParams& p, int id) {
@@ -470,7 +538,8 @@ const char* conv_gemm_last_config() { return g_last_cfg; }
 
 KernelProfiler* g_conv_prof = nullptr;
 
-void KernelProfiler::next_pair(hipEvent_t* a, hipEvent_t* b, double fl) {
+void KernelProfiler::next_pair(hipEvent_t* a, hipEvent_t* b, double fl, const std::string& what) {
+  labels.push_back(what);
   if (used + 2 > (int)events.size()) {
     const size_t old = events.size();
     events.resize(old + 1024);
@@ -487,9 +556,22 @@ void KernelProfiler::collect(int* launches, double* total_ms, double* total_flop
     float t = 0;
     HIP_CHECK(hipEventElapsedTime(&t, events[i], events[i + 1]));
     ms += t; fl += flops[i / 2];
+    if (verbose) {
+      auto& e = per_shape[labels[i / 2]];
+      e.n += 1; e.ms += t; e.flops += flops[i / 2];
+    }
+  }
+  if (verbose) {
+    std::vector<std::pair<std::string, Entry>> v(per_shape.begin(), per_shape.end());
+    std::sort(v.begin(), v.end(), [](const auto& x, const auto& y) { return x.second.ms > y.second.ms; });
+    fprintf(stderr, "[conv_gemm] %d launches %.3f ms %.1f TFLOP/s\n", used / 2, ms, fl / ms * 1e-9);
+    for (auto& kv : v)
+      fprintf(stderr, "  %-58s n=%4d %8.3f ms %7.1f us/launch %7.1f TF/s\n", kv.first.c_str(), kv.second.n,
+              kv.second.ms, kv.second.ms / kv.second.n * 1e3, kv.second.flops / kv.second.ms * 1e-9);
+    per_shape.clear();
   }
   *launches = used / 2; *total_ms = ms; *total_flops = fl;
-  used = 0; flops.clear();
+  used = 0; flops.clear(); labels.clear();
 }
 KernelProfiler::~KernelProfiler() { for (auto e : events) (void)hipEventDestroy(e); }
 
@@ -525,19 +607,39 @@ int tuned_config(hipStream_t st, const ConvGemmParams& p, bool k64) {
   HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
   int best = pick_config(p);
   float best_ms = 1e30f;
-  for (int i = 0; i < kNumCfgs; ++i) {
+  // split-K candidates only where 128x128 tiles cannot fill the 256 CUs (deep-K 3x3 convs at 8x8 / 16x16)
+  const SplitKWorkspace& sk = g_conv_splitk;
+  const int64_t t128 = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 128) * p.nbatch;
+  const int nk = p.Ktot / (k64 ? 64 : 32);
+  static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16};
+  for (int i = 0; i < kNumCfgs; ++i)
+  for (int si = 0; si < 8; ++si) {
     const CfgInfo& c = kCfgs[i];
+    const int split = kSplits[si];
     if (p.act == ACT_GEGLU && c.TN < 64) continue;
     if (c.BM >= 256 && p.M < 256) continue;
+    const int64_t tiles = (int64_t)ceil_div(p.M, c.BM) * ceil_div(p.N, c.BN) * p.nbatch;
+    if (split > 1) {
+      if (!sk.scratch || t128 >= 200 || nk < 8 * split || tiles * split > 1536) continue;
+      if ((size_t)tiles * split * c.BM * c.BN * 4 > sk.scratch_bytes || tiles > sk.nflags) continue;
+    }
+    q.splitk = split; q.sk_scratch = sk.scratch; q.sk_flags = sk.flags;
     auto run = [&]() { if (k64) dispatch<64>(st, q, c.id); else dispatch<32>(st, q, c.id); };
+    auto timed = [&](int reps) {
+      HIP_CHECK(hipEventRecord(e0, st));
+      for (int r = 0; r < reps; ++r) run();
+      HIP_CHECK(hipEventRecord(e1, st));
+      HIP_CHECK(hipEventSynchronize(e1));
+      float t = 0;
+      HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+      return t / reps;
+    };
     run();  // warm
-    HIP_CHECK(hipEventRecord(e0, st));
-    run(); run();
-    HIP_CHECK(hipEventRecord(e1, st));
-    HIP_CHECK(hipEventSynchronize(e1));
-    float ms = 0;
-    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    if (ms < best_ms) { best_ms = ms; best = c.id; }
+    float ms = timed(2);
+    // short launches: event granularity and launch gaps dominate a 2-launch sample
+    const int reps = (int)fminf(24.f, fmaxf(2.f, 0.4f / fmaxf(ms, 1e-3f)));
+    ms = fminf(ms, fminf(timed(reps), timed(reps)));
+    if (ms < best_ms) { best_ms = ms; best = c.id | (split << 8); }
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   tab[key] = best;
@@ -557,6 +659,10 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   if (p.act == ACT_GEGLU) CD_CHECK(p.N % 64 == 0, "GEGLU needs packed N %% 64 == 0");
   const bool k64 = (p.C0 % 64 == 0) && (p.C1 % 64 == 0);
   int id = p.tile ? p.tile : tuned_config(st, p, k64);
+  ConvGemmParams pk = p;
+  if ((id >> 8) > 1) pk.splitk = id >> 8;  // from the tuner, or packed into an explicit `tile` (tests, sweeps)
+  id &= 0xff;
+  if (pk.splitk > 1 && !pk.sk_scratch) { pk.sk_scratch = g_conv_splitk.scratch; pk.sk_flags = g_conv_splitk.flags; }
   const CfgInfo* ci = nullptr;
   for (int i = 0; i < kNumCfgs; ++i) if (kCfgs[i].id == id) ci = &kCfgs[i];
   CD_CHECK(ci, "conv_gemm: unknown tile configuration %d", id);
@@ -565,15 +671,19 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   KernelProfiler* prof = g_conv_prof;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (prof && prof->enabled) {
-    prof->next_pair(&e0, &e1, 2.0 * (double)p.M * (double)p.N * (double)p.Ktot * (double)p.nbatch);
+    char what[96] = "";
+    if (prof->verbose)
+      snprintf(what, sizeof(what), "M%d N%d K%d k%d s%d%s%s z%d act%d | %s x%d", p.M, p.N, p.Ktot, p.KH, p.stride,
+               p.up ? " up" : "", p.src1 ? " cat" : "", p.nbatch, p.act, ci->name, pk.splitk > 1 ? pk.splitk : 1);
+    prof->next_pair(&e0, &e1, 2.0 * (double)p.M * (double)p.N * (double)p.Ktot * (double)p.nbatch, what);
     (void)hipEventRecord(e0, st);
   }
   struct Closer {  // record the stop event on every exit path
     hipEvent_t e; hipStream_t s;
     ~Closer() { if (e) (void)hipEventRecord(e, s); }
   } closer{e1, st};
-  if (k64) dispatch<64>(st, p, id);
-  else dispatch<32>(st, p, id);
+  if (k64) dispatch<64>(st, pk, id);
+  else dispatch<32>(st, pk, id);
 }
 
 int conv_gemm_num_configs() { return kNumCfgs; }

@@ -1,5 +1,7 @@
 // Launcher declarations for the hand-written gfx950 kernels (implementation: *.hip in this dir).
 #pragma once
+#include <map>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -76,8 +78,20 @@ struct ConvGemmParams {
   // per channel over each 32-row block); null = off. Not available with GEGLU.
   float* stats = nullptr;
   const bf16_t* zeros = nullptr;  // >= 256 B of zeros (masked rows / padding taps)
-  int tile = 0;                   // 0 = auto
+  int tile = 0;                   // 0 = auto (tile configuration AND split factor from the autotuner)
+  // split-K (deep-K layers whose output tiles cannot fill 256 CUs): K is cut in `splitk` ranges, fp32
+  // partial tiles meet in sk_scratch and the last arrival sums them in split order. 0/1 = off.
+  int splitk = 0;
+  float* sk_scratch = nullptr;    // defaults to g_conv_splitk when splitk > 1
+  int* sk_flags = nullptr;
 };
+struct SplitKWorkspace {
+  float* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  int* flags = nullptr;  // zero-initialised arrival counters, one per output tile
+  int nflags = 0;
+};
+extern SplitKWorkspace g_conv_splitk;
 void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p);
 const char* conv_gemm_last_config();
 int conv_gemm_num_configs();
@@ -90,8 +104,12 @@ struct KernelProfiler {
   bool enabled = false;
   std::vector<hipEvent_t> events;
   std::vector<double> flops;
+  std::vector<std::string> labels;
   int used = 0;
-  void next_pair(hipEvent_t* a, hipEvent_t* b, double fl);
+  bool verbose = false;  // CYCLEDIFF_GEMM_LOG=1: collect() prints a per-shape table to stderr
+  struct Entry { int n = 0; double ms = 0, flops = 0; };
+  std::map<std::string, Entry> per_shape;
+  void next_pair(hipEvent_t* a, hipEvent_t* b, double fl, const std::string& what);
   void collect(int* launches, double* total_ms, double* total_flops);
   ~KernelProfiler();
 };

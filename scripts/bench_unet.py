@@ -33,3 +33,9 @@ torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
 print("B=%d: %.2f ms/forward  -> %.1f TFLOP/s (803.3 GFLOP/sample)" % (B, ms, B * 803.3 / ms))
 print("workspace high water %.2f GB" % (eng.workspace_high_water() / 2 ** 30))
+if len(sys.argv) > 3 and sys.argv[3] == "gemmlog":  # CYCLEDIFF_GEMM_LOG=1: per-shape in-situ GEMM table
+    eng.prof_enable(True)
+    eng.unet_forward(net, x, t, ctx)
+    torch.cuda.synchronize()
+    print("conv_gemm in situ:", eng.prof_collect())
+    eng.prof_enable(False)

@@ -70,6 +70,14 @@ CONV_CASES = [
     ("3x3_ragged_M", 1, 64, 0, 10, 10, 64, 3, 1, 1, False, False, True, False, True, 0, 0),
     ("3x3_1280_8x8", 2, 1280, 0, 8, 8, 1280, 3, 1, 1, False, False, True, True, True, 0, 0),
     ("3x3_2560_1280_skip", 1, 1280, 1280, 8, 8, 1280, 3, 1, 1, False, False, True, False, False, 0, 0),
+    # split-K (tile | split << 8): K ranges that start mid-tap / in the second concat source, ragged M,
+    # more splits than K steps (empty ranges), fused epilogue after the fix-up
+    ("3x3_1280_8x8_split4", 2, 1280, 0, 8, 8, 1280, 3, 1, 1, False, False, True, True, True, 0, 8 | (4 << 8)),
+    ("3x3_2560_1280_skip_split7", 1, 1280, 1280, 8, 8, 1280, 3, 1, 1, False, False, True, False, False, 0, 2 | (7 << 8)),
+    ("3x3_ragged_M_split2", 1, 64, 0, 10, 10, 64, 3, 1, 1, False, False, True, False, True, 0, 3 | (2 << 8)),
+    ("3x3_ragged_M_split8", 1, 64, 0, 10, 10, 64, 3, 1, 1, False, False, True, False, True, 0, 1 | (8 << 8)),
+    ("3x3_concat_k32_split3", 2, 64, 32, 16, 16, 96, 3, 1, 1, False, False, True, False, False, 0, 2 | (3 << 8)),
+    ("3x3_stride2_split2_silu", 2, 128, 0, 16, 16, 128, 3, 2, 1, False, False, True, False, False, 1, 3 | (2 << 8)),
 ]
 
 
@@ -102,6 +110,19 @@ def test_conv2d(engine, report, case):
                       resid=res, act=act, tile=tile)
     # the op wrapper returns the fp32 epilogue result (out_f32 path): only operand rounding remains
     _check(report, "conv2d/" + name, got, ref, rel=5e-3, mean=2e-3)
+
+
+def test_conv_splitk_repeatable(engine, report):
+    # the last-arriving block sums the partial tiles in split order and resets the tile counter: repeated
+    # launches (and different tile configurations with the same split) give identical bits
+    g = torch.Generator().manual_seed(11)
+    x = r16(torch.randn(2, 640, 8, 8, generator=g))
+    w = r16(torch.randn(640, 640, 3, 3, generator=g) / math.sqrt(640 * 9))
+    outs = [_ops.conv2d(engine, x, w, pad=1, tile=t | (5 << 8)) for t in (2, 2, 3, 8, 2)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    ref = F.conv2d(x, w, None, padding=1)
+    _check(report, "conv2d/splitk_repeat", outs[0], ref, rel=5e-3, mean=2e-3)
 
 
 def test_conv_geglu(engine, report):
