@@ -52,7 +52,7 @@ struct TileCfg {
   static_assert(A_IPW >= 1 && B_IPW >= 1, "tile too small for the wave count");
   static_assert(A_IPW * RPI * NW == BM && B_IPW * RPI * NW == BN, "tile rows must split evenly over waves");
   static_assert(MT >= 1 && NT >= 1, "wave tile");
-  static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
+  static_assert(NSTAGE >= 2 && NSTAGE <= 8, "ring depth");
   static_assert((NSTAGE - 2) * LPT <= 63, "vmcnt field");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
@@ -286,25 +286,34 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
   // one to arrive sums all partials in split order (so the result does not depend on arrival order) and
   // runs the epilogue; the tile's arrival counter is reset for the next launch.
   if (nsplit > 1) {
-    constexpr int TILE_ELEMS = BM * BN;
-    float* part0 = p.sk_scratch + ((int64_t)zb * ntiles + tile) * nsplit * TILE_ELEMS;
-    float* mine = part0 + (int64_t)sidx * TILE_ELEMS + tid;
+    // Partial tiles travel with sc1 (device-coherent, write-through / L2-bypassing) 16-byte stores and
+    // loads, so no release/acquire fence is needed around the counter: a fence here would be a full L2
+    // write-back + invalidate per block, which costs more than the K loop it saves.
+    constexpr int TILE_BYTES = BM * BN * 4;
+    constexpr int kSc1 = 16;  // buffer cache-policy bit: sc1
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    float* part0 = p.sk_scratch + ((int64_t)zb * ntiles + tile) * nsplit * (BM * BN);
+    const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc((void*)part0, 0, kRange, 0x00020000);
+    // register layout: quad q of accumulator tile (i, j) of every lane is one 16-byte vector
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mine[((i * NT + j) * 16 + r) * (64 * NW)] = acc[i][j][r];
-    __threadfence();
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          const int off = sidx * TILE_BYTES + (((i * NT + j) * 4 + q) * (64 * NW) + tid) * 16;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsp, off, 0, kSc1);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial is out before it is counted
     __syncthreads();
     int* flag = p.sk_flags + zb * ntiles + tile;
-    if (tid == 0) *(volatile int*)smem = atomicAdd(flag, 1);
+    if (tid == 0) *(volatile int*)smem = __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int arrived = *(volatile int*)smem;
     __syncthreads();
     if (arrived != nsplit - 1) return;
-    __threadfence();
-    if (tid == 0) *flag = 0;
+    if (tid == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -312,14 +321,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     for (int sp = 0; sp < nsplit; ++sp) {
-      const float* src = part0 + (int64_t)sp * TILE_ELEMS + tid;
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            acc[i][j][r] += __builtin_nontemporal_load(src + ((i * NT + j) * 16 + r) * (64 * NW));
+          for (int q = 0; q < 4; ++q) {
+            const int off = sp * TILE_BYTES + (((i * NT + j) * 4 + q) * (64 * NW) + tid) * 16;
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsp, off, 0, kSc1));
+            acc[i][j][4 * q] += v[0]; acc[i][j][4 * q + 1] += v[1];
+            acc[i][j][4 * q + 2] += v[2]; acc[i][j][4 * q + 3] += v[3];
+          }
     }
   }
 
@@ -491,6 +503,12 @@ const CfgInfo kCfgs[] = {
     {9, 256, 64, 64, "256x64 w8x1 s4"},
     {10, 128, 128, 64, "128x128 w2x2 s4"},
     {11, 64, 128, 64, "64x128 w2x2 s4"},
+    {12, 128, 64, 64, "128x64 w4x1 s3"},
+    {13, 256, 64, 64, "256x64 w8x1 s3"},
+    {14, 128, 128, 64, "128x128 w4x2 s3"},
+    {15, 64, 64, 32, "64x64 w2x2 s8"},
+    {16, 128, 64, 64, "128x64 w4x1 s6"},
+    {17, 64, 128, 64, "64x128 w2x2 s6"},
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -515,6 +533,15 @@ void dispatch(hipStream_t st, const ConvGemmParams& p, int id) {
       break;
     case 10: launch_cfg<128, 128, BK, 2, 2, 4>(st, p); break;
     case 11: launch_cfg<64, 128, BK, 2, 2, 4>(st, p); break;
+    case 12: launch_cfg<128, 64, BK, 4, 1, 3>(st, p); break;
+    case 13:
+      if constexpr (BK == 64) launch_cfg<256, 64, 64, 8, 1, 3>(st, p);
+      else launch_cfg<128, 64, 32, 4, 1, 3>(st, p);
+      break;
+    case 14: launch_cfg<128, 128, BK, 4, 2, 3>(st, p); break;
+    case 15: launch_cfg<64, 64, BK, 2, 2, 8>(st, p); break;
+    case 16: launch_cfg<128, 64, BK, 4, 1, 6>(st, p); break;
+    case 17: launch_cfg<64, 128, BK, 2, 2, 6>(st, p); break;
     default: CD_CHECK(false, "conv_gemm: unknown tile configuration %d", id);
   }
 }
@@ -612,19 +639,25 @@ int tuned_config(hipStream_t st, const ConvGemmParams& p, bool k64) {
   const int64_t t128 = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 128) * p.nbatch;
   const int nk = p.Ktot / (k64 ? 64 : 32);
   static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16};
+  // short-K contractions (1x1 convs / linears) also try the BK=32 variants: half the LDS per stage, so
+  // twice the resident blocks to hide the prologue / epilogue of a 5-10 step K loop
+  const int nbk = (k64 && p.Ktot <= 1280) ? 2 : 1;
+  for (int bi = 0; bi < nbk; ++bi)
   for (int i = 0; i < kNumCfgs; ++i)
   for (int si = 0; si < 8; ++si) {
     const CfgInfo& c = kCfgs[i];
     const int split = kSplits[si];
+    const bool use64 = k64 && bi == 0;
+    if (bi == 1 && split > 1) continue;
     if (p.act == ACT_GEGLU && c.TN < 64) continue;
     if (c.BM >= 256 && p.M < 256) continue;
     const int64_t tiles = (int64_t)ceil_div(p.M, c.BM) * ceil_div(p.N, c.BN) * p.nbatch;
     if (split > 1) {
-      if (!sk.scratch || t128 >= 200 || nk < 8 * split || tiles * split > 1536) continue;
+      if (!sk.scratch || t128 >= 400 || nk < 4 * split || tiles * split > 2048) continue;
       if ((size_t)tiles * split * c.BM * c.BN * 4 > sk.scratch_bytes || tiles > sk.nflags) continue;
     }
     q.splitk = split; q.sk_scratch = sk.scratch; q.sk_flags = sk.flags;
-    auto run = [&]() { if (k64) dispatch<64>(st, q, c.id); else dispatch<32>(st, q, c.id); };
+    auto run = [&]() { if (use64) dispatch<64>(st, q, c.id); else dispatch<32>(st, q, c.id); };
     auto timed = [&](int reps) {
       HIP_CHECK(hipEventRecord(e0, st));
       for (int r = 0; r < reps; ++r) run();
@@ -639,7 +672,7 @@ int tuned_config(hipStream_t st, const ConvGemmParams& p, bool k64) {
     // short launches: event granularity and launch gaps dominate a 2-launch sample
     const int reps = (int)fminf(24.f, fmaxf(2.f, 0.4f / fmaxf(ms, 1e-3f)));
     ms = fminf(ms, fminf(timed(reps), timed(reps)));
-    if (ms < best_ms) { best_ms = ms; best = c.id | (split << 8); }
+    if (ms < best_ms) { best_ms = ms; best = c.id | (split << 8) | ((k64 && !use64) ? (1 << 16) : 0); }
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   tab[key] = best;
@@ -657,8 +690,10 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   CD_CHECK(((uintptr_t)p.src0 & 15) == 0 && ((uintptr_t)p.wgt & 15) == 0, "conv_gemm: 16-B alignment");
   CD_CHECK((p.ld0 % 8) == 0 && (p.src1 == nullptr || (p.ld1 % 8) == 0), "conv_gemm: ld must be a multiple of 8");
   if (p.act == ACT_GEGLU) CD_CHECK(p.N % 64 == 0, "GEGLU needs packed N %% 64 == 0");
-  const bool k64 = (p.C0 % 64 == 0) && (p.C1 % 64 == 0);
+  bool k64 = (p.C0 % 64 == 0) && (p.C1 % 64 == 0);
   int id = p.tile ? p.tile : tuned_config(st, p, k64);
+  if (id & (1 << 16)) k64 = false;  // tuner (or an explicit tile | 1<<16) asks for the BK=32 variant
+  id &= 0xffff;
   ConvGemmParams pk = p;
   if ((id >> 8) > 1) pk.splitk = id >> 8;  // from the tuner, or packed into an explicit `tile` (tests, sweeps)
   id &= 0xff;
@@ -675,6 +710,7 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
     if (prof->verbose)
       snprintf(what, sizeof(what), "M%d N%d K%d k%d s%d%s%s z%d act%d | %s x%d", p.M, p.N, p.Ktot, p.KH, p.stride,
                p.up ? " up" : "", p.src1 ? " cat" : "", p.nbatch, p.act, ci->name, pk.splitk > 1 ? pk.splitk : 1);
+    if (prof->verbose && !k64) strncat(what, " bk32", sizeof(what) - strlen(what) - 1);
     prof->next_pair(&e0, &e1, 2.0 * (double)p.M * (double)p.N * (double)p.Ktot * (double)p.nbatch, what);
     (void)hipEventRecord(e0, st);
   }

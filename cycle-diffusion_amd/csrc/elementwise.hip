@@ -98,10 +98,30 @@ __global__ __launch_bounds__(256) void k_vec_linear(const float* __restrict__ x,
   const float* xr = x + (int64_t)b * ldx;
   const float* wr = W + (int64_t)n * K;
   float acc = 0.f;
-  for (int k = lane; k < K; k += 64) {
-    float xv = xr[k];
-    if (silu_in) xv = silu_f(xv);
-    acc += xv * wr[k];
+  if ((K & 3) == 0 && (ldx & 3) == 0) {
+    // 16 B per lane and four independent row segments in flight: the 100 MB fused time-embedding
+    // projection is a pure weight stream, one load at a time per wave leaves it latency-bound
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nv = K >> 2;
+    for (int v0 = lane; v0 < nv; v0 += 256) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int v = v0 + u * 64;
+        if (v < nv) {
+          const f32x4 wv = __builtin_nontemporal_load((const f32x4*)wr + v);
+          f32x4 xv = *((const f32x4*)xr + v);
+          if (silu_in) { xv[0] = silu_f(xv[0]); xv[1] = silu_f(xv[1]); xv[2] = silu_f(xv[2]); xv[3] = silu_f(xv[3]); }
+          a4[u] += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+        }
+      }
+    }
+    acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  } else {
+    for (int k = lane; k < K; k += 64) {
+      float xv = xr[k];
+      if (silu_in) xv = silu_f(xv);
+      acc += xv * wr[k];
+    }
   }
 #pragma unroll
   for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
