@@ -15,6 +15,8 @@
 // global stores are 16 B per lane with bias / time-embedding / residual / SiLU / GELU / GEGLU fused.
 // Per-element reduction order is k-ascending for every tile configuration, so results do not
 // depend on which configuration (or batch size) is chosen.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -614,7 +616,42 @@ struct ShapeKey {
   int v[14];
   bool operator<(const ShapeKey& o) const { return memcmp(v, o.v, sizeof(v)) < 0; }
 };
-std::map<ShapeKey, int>& tune_table() { static std::map<ShapeKey, int> t; return t; }
+// CYCLEDIFF_TUNE_CACHE=<file>: choices are appended to / preloaded from a text file (15 ints per line), so a
+// second process (e.g. a rocprofv3 run whose kernel statistics should not contain tuning launches) starts tuned.
+const char* tune_cache_path() {
+  static const char* p = getenv("CYCLEDIFF_TUNE_CACHE");
+  return (p && p[0]) ? p : nullptr;
+}
+std::map<ShapeKey, int>& tune_table() {
+  static std::map<ShapeKey, int> t;
+  static bool loaded = false;
+  if (!loaded) {
+    loaded = true;
+    if (const char* path = tune_cache_path()) {
+      if (FILE* f = fopen(path, "r")) {
+        ShapeKey k; int val;
+        for (;;) {
+          int got = 0;
+          for (int i = 0; i < 14; ++i) got += fscanf(f, "%d", &k.v[i]);
+          got += fscanf(f, "%d", &val);
+          if (got != 15) break;
+          t[k] = val;
+        }
+        fclose(f);
+      }
+    }
+  }
+  return t;
+}
+void tune_cache_append(const ShapeKey& k, int val) {
+  const char* path = tune_cache_path();
+  if (!path) return;
+  if (FILE* f = fopen(path, "a")) {
+    for (int i = 0; i < 14; ++i) fprintf(f, "%d ", k.v[i]);
+    fprintf(f, "%d\n", val);
+    fclose(f);
+  }
+}
 
 int tuned_config(hipStream_t st, const ConvGemmParams& p, bool k64) {
   ConvTuner& tu = g_conv_tuner;
@@ -676,6 +713,7 @@ int tuned_config(hipStream_t st, const ConvGemmParams& p, bool k64) {
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   tab[key] = best;
+  tune_cache_append(key, best);
   ++tu.shapes_tuned;
   return best;
 }

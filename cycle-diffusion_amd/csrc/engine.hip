@@ -260,8 +260,10 @@ Act groupnorm_fwd(Ctx& c, const GNW& w, const Act& x, const Act* x2, bool silu, 
   Act y = alloc_act(c, x.B, x.H, x.W, C);
   p.y = y.p;
   p.S = groupnorm_slabs(p.B, p.HW, C);
-  CD_CHECK((size_t)p.B * p.S * p.G * 2 <= c.gn_partial_floats, "groupnorm: partial workspace too small");
+  const size_t part_floats = round_up((size_t)p.B * p.S * p.G * 2, (size_t)64);
+  CD_CHECK(part_floats + (size_t)p.B * 2 * C <= c.gn_partial_floats, "groupnorm: workspace too small");
   p.partial = c.gn_partial;
+  p.coef = c.gn_partial + part_floats;
   if (x.stats && x.ld == x.C && (!x2 || (x2->stats && x2->ld == x2->C))) {
     p.pre0 = x.stats;
     p.pre1 = x2 ? x2->stats : nullptr;

@@ -145,6 +145,7 @@ struct GroupNormParams {
   bf16_t* y = nullptr;          // [B][HW][C] dense
   float* partial = nullptr;     // workspace [B][S][G][2]
   int S = 0;
+  float* coef = nullptr;        // workspace [B][2][C]: per-channel multiply-add coefficients
   // statistics already produced by the conv epilogue that wrote x / x1 (ConvGemmParams::stats layout,
   // [B*HW/32][2][C]): when set, the stats pass is replaced by a small per-(image, group) fold
   const float* pre0 = nullptr;

@@ -24,6 +24,27 @@ __device__ inline const bf16_t* gn_src(const GroupNormParams& p, int b, int row,
   return p.x1 + ((int64_t)b * p.HW + row) * p.ld1;
 }
 
+// statistics, affine and FiLM folded into one per-(image, channel) multiply-add: y = x*al + be;
+// coef[b][0][c] = al, coef[b][1][c] = be
+__device__ inline void gn_write_coef(const GroupNormParams& p, int b, int c, float sum, float sumsq, int cpg) {
+  const int C = p.C0 + p.C1;
+  const float n = (float)cpg * (float)p.HW;
+  const float mean = sum / n;
+  float var = sumsq / n - mean * mean;
+  var = var < 0.f ? 0.f : var;
+  const float rstd = 1.0f / sqrtf(var + p.eps);
+  float a = rstd * p.gamma[c];
+  float bb = p.beta[c] - mean * a;
+  if (p.film) {
+    const float* fl = p.film + (int64_t)b * p.film_ld;
+    const float sc = 1.0f + fl[c];
+    a *= sc;
+    bb = bb * sc + fl[C + c];
+  }
+  float* o = p.coef + (int64_t)b * 2 * C;
+  o[c] = a; o[C + c] = bb;
+}
+
 // grid (S, B). Each block reduces a slab of rows for all groups; thread owns a fixed set of 8-channel
 // vectors so per-channel sums stay in registers; fixed-order LDS reduction -> partial[b][s][g][2].
 __global__ __launch_bounds__(256) void k_gn_stats(GroupNormParams p, int rows_per_slab) {
@@ -125,75 +146,82 @@ __global__ __launch_bounds__(256) void k_gn_fold(GroupNormParams p) {
     float* o = p.partial + ((int64_t)b * p.G + g) * 2;
     o[0] = rs[0]; o[1] = rq[0];
   }
+  if (tid < cpg) gn_write_coef(p, b, g * cpg + tid, rs[0], rq[0], cpg);
 }
 
-// grid (row_chunks, B): y = (x-mean)*rstd*gamma+beta [FiLM] [SiLU]
+// grid (B): statistics partial[b][S][G][2] -> per-channel multiply-add coefficients (non-fused path)
+__global__ __launch_bounds__(256) void k_gn_coef(GroupNormParams p) {
+  __shared__ float s_a[64], s_q[64];
+  const int C = p.C0 + p.C1;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int cpg = C / p.G;
+  if (tid < p.G) {
+    float a = 0.f, q = 0.f;
+    for (int s = 0; s < p.S; ++s) {  // fixed order: deterministic
+      const float* o = p.partial + (((int64_t)b * p.S + s) * p.G + tid) * 2;
+      a += o[0]; q += o[1];
+    }
+    s_a[tid] = a; s_q[tid] = q;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) gn_write_coef(p, b, c, s_a[c / cpg], s_q[c / cpg], cpg);
+}
+
+// grid (row_chunks, B): y = x*al[c] + be[c] [SiLU]. A thread owns fixed 8-channel vectors (its 16
+// coefficients stay in registers) and walks rows `rif` apart, four independent 16-byte loads in flight;
+// blocks are small (a few KB) so every CU holds several and the pass runs at HBM speed.
 __global__ __launch_bounds__(256) void k_gn_apply(GroupNormParams p, int rows_per_block) {
-  __shared__ float s_mean[64], s_rstd[64];
   const int C = p.C0 + p.C1;
   const int nvec = C >> 3;
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
-  const int cpg = C / p.G;
-  if (tid < p.G) {
-    float a = 0.f, q = 0.f;
-    for (int s = 0; s < p.S; ++s) {
-      const float* o = p.partial + (((int64_t)b * p.S + s) * p.G + tid) * 2;
-      a += o[0]; q += o[1];
-    }
-    const float n = (float)cpg * (float)p.HW;
-    const float mean = a / n;
-    float var = q / n - mean * mean;
-    var = var < 0.f ? 0.f : var;
-    s_mean[tid] = mean;
-    s_rstd[tid] = 1.0f / sqrtf(var + p.eps);
-  }
-  __syncthreads();
-  // fold statistics, affine and FiLM into one per-channel multiply-add: y = x*al[c] + be[c]
-  extern __shared__ __attribute__((aligned(16))) float sh[];
-  float* al = sh;
-  float* be = sh + C;
-  for (int c = tid; c < C; c += 256) {
-    const int g = c / cpg;
-    float a = s_rstd[g] * p.gamma[c];
-    float bb = p.beta[c] - s_mean[g] * a;
-    if (p.film) {
-      const float* fl = p.film + (int64_t)b * p.film_ld;
-      const float sc = 1.0f + fl[c];
-      a *= sc;
-      bb = bb * sc + fl[C + c];
-    }
-    al[c] = a; be[c] = bb;
-  }
-  __syncthreads();
   const int row_begin = blockIdx.x * rows_per_block;
   const int row_end = min(p.HW, row_begin + rows_per_block);
-  // thread owns fixed 8-channel vectors (coefficients stay in registers), rows strided across threads
   int rif, vpt;
   if (nvec <= 256) { rif = 256 / nvec; vpt = 1; }
   else { rif = 1; vpt = (nvec + 255) >> 8; }
   const int r0 = (nvec <= 256) ? tid / nvec : 0;
   const int v0 = (nvec <= 256) ? tid % nvec : tid;
   if (nvec <= 256 && tid >= nvec * rif) return;
+  const float* coef = p.coef + (int64_t)b * 2 * C;
   for (int j = 0; j < vpt; ++j) {
     const int v = v0 + j * 256;
     if (v >= nvec) break;
     const int c = v * 8;
     float ca[8], cb[8];
+    {
+      const f32x4 a0 = *(const f32x4*)(coef + c), a1 = *(const f32x4*)(coef + c + 4);
+      const f32x4 b0 = *(const f32x4*)(coef + C + c), b1 = *(const f32x4*)(coef + C + c + 4);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { ca[e] = al[c + e]; cb[e] = be[c + e]; }
-    for (int row = row_begin + r0; row < row_end; row += rif) {
-      int off;
-      const bf16_t* base = gn_src(p, b, row, c, off);
-      float f[8];
-      unpack8(*(const uint4*)(base + off), f);
+      for (int e = 0; e < 4; ++e) { ca[e] = a0[e]; ca[4 + e] = a1[e]; cb[e] = b0[e]; cb[4 + e] = b1[e]; }
+    }
+    for (int row = row_begin + r0; row < row_end; row += 4 * rif) {
+      uint4 raw[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float y = f[e] * ca[e] + cb[e];
-        if (p.silu) y = silu_f(y);
-        f[e] = y;
+      for (int u = 0; u < 4; ++u) {
+        const int r = row + u * rif;
+        raw[u] = make_uint4(0, 0, 0, 0);
+        if (r < row_end) {
+          int off;
+          const bf16_t* base = gn_src(p, b, r, c, off);
+          raw[u] = *(const uint4*)(base + off);
+        }
       }
-      *(uint4*)(p.y + ((int64_t)b * p.HW + row) * C + c) = pack8(f);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = row + u * rif;
+        if (r < row_end) {
+          float f[8];
+          unpack8(raw[u], f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float y = f[e] * ca[e] + cb[e];
+            if (p.silu) y = silu_f(y);
+            f[e] = y;
+          }
+          *(uint4*)(p.y + ((int64_t)b * p.HW + r) * C + c) = pack8(f);
+        }
+      }
     }
   }
 }
@@ -294,6 +322,8 @@ void launch_groupnorm(hipStream_t st, const GroupNormParams& p) {
   CD_CHECK(p.partial && p.S > 0, "groupnorm: workspace missing");
   const int nvec = C >> 3;
   const int rif = nvec <= 256 ? 256 / nvec : 1;
+  CD_CHECK(p.coef, "groupnorm: coefficient workspace missing");
+  CD_CHECK(C / p.G <= 256, "groupnorm: more than 256 channels per group");
   GroupNormParams q = p;
   if (p.pre0 && (p.C1 == 0 || p.pre1) && (p.HW % 32) == 0) {
     q.S = 1;  // statistics came out of the producing convs' epilogues: fold them per (image, group)
@@ -302,11 +332,13 @@ void launch_groupnorm(hipStream_t st, const GroupNormParams& p) {
     const int rows_per_slab = ceil_div(p.HW, p.S);
     const size_t lds = (size_t)rif * C * 2 * sizeof(float);
     hipLaunchKernelGGL(k_gn_stats, dim3(p.S, p.B), dim3(256), lds, st, p, rows_per_slab);
+    hipLaunchKernelGGL(k_gn_coef, dim3(p.B), dim3(256), 0, st, p);
   }
-  int rows_per_block = 32768 / C;  // ~64 KB of 16-bit data per block
-  if (rows_per_block < 1) rows_per_block = 1;
-  hipLaunchKernelGGL(k_gn_apply, dim3(ceil_div(p.HW, rows_per_block), p.B), dim3(256),
-                     (size_t)C * 2 * sizeof(float), st, q, rows_per_block);
+  // ~2048 blocks per launch where the tensor allows it; at least one unrolled batch of rows per thread
+  int rows_per_block = (int)(((int64_t)p.HW * p.B + 2047) / 2048);
+  const int unit = 4 * rif;
+  rows_per_block = ceil_div(rows_per_block, unit) * unit;
+  hipLaunchKernelGGL(k_gn_apply, dim3(ceil_div(p.HW, rows_per_block), p.B), dim3(256), 0, st, q, rows_per_block);
 }
 
 void launch_layernorm(hipStream_t st, const bf16_t* x, int ldx, bf16_t* y, int ldy, int rows,
