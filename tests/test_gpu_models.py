@@ -15,8 +15,11 @@ from oracle import nets, samplers
 
 pytestmark = pytest.mark.gpu
 
-NET_REL = 3e-2
-NET_MEAN = 1.5e-2
+# Bounds are ~3x the errors measured on MI355X with the default fp16 storage (gpurun_out/parity_report.json:
+# networks 1.1e-3..2.7e-3 of the output range); the bf16 build (CD_ACT_FP16=0) has 8x the rounding step.
+FMT = 1.0 if _ffi.load_library().cd_act_format() == 1 else 8.0
+NET_REL = 8e-3 * FMT
+NET_MEAN = 8e-3 * FMT
 
 
 def _stats(got, ref):
@@ -117,7 +120,7 @@ def test_latent_cycle_tiny(engine, report):
     zn = zc.flatten(2).norm(dim=2)
     rel = ((zn - torch.as_tensor(fx["z_norms"])).abs() / torch.as_tensor(fx["z_norms"])).max().item()
     report.add("sampler/latent_z_norm_rel", rel=rel)
-    assert rel < 0.25
+    assert rel < 1e-3 * FMT  # measured 2.8e-5
     coef_d = sch.coef_decode()
     x_same = engine.ddim_decode(net, _ffi.CD_SCHED_DDIM, z, coef_d, ctx_c=c.cuda(), ctx_uc=uc.cuda(), guidance=1.0)
     cyc = (x_same.cpu() - x0).abs().max().item()
@@ -125,7 +128,7 @@ def test_latent_cycle_tiny(engine, report):
     # the engine's U-Net is deterministic, so its own cycle closes to fp32 round-off of the scheduler math
     assert cyc < 5e-3, cyc
     x_tgt = engine.ddim_decode(net, _ffi.CD_SCHED_DDIM, z, coef_d, ctx_c=c2.cuda(), ctx_uc=uc.cuda(), guidance=3.0)
-    _check(report, "sampler/latent_x_tgt", x_tgt, fx["x_tgt"], rel=0.15, mean=0.06)
+    _check(report, "sampler/latent_x_tgt", x_tgt, fx["x_tgt"], rel=3e-2 * FMT, mean=1.5e-2 * FMT)  # measured 6e-3 / 3e-3
 
 
 def _c1(engine, report, fx_name, steps, eta, sample_type):
@@ -145,7 +148,7 @@ def _c1(engine, report, fx_name, steps, eta, sample_type):
     zr = torch.as_tensor(fx["z_sub"][:, 1:])
     zerr = ((zs - zr).flatten(2).abs().max(dim=2).values / zr.flatten(2).abs().max(dim=2).values)[0]
     report.add("sampler/" + fx_name + "_z", rel_first=float(zerr[0]), rel_mid=float(zerr[1]), rel_last=float(zerr[2]))
-    assert zerr[0] < 2e-2 and zerr[1] < 2e-2 and zerr[2] < 0.25, zerr
+    assert zerr[0] < 6e-3 * FMT and zerr[1] < 6e-3 * FMT and zerr[2] < 2e-2 * FMT, zerr  # measured ~1e-3
     x = engine.ddim_decode(net, sch.kind, z, sch.coef_decode(), n_eps=steps - 1, noise_tail=last[None].cuda())
     out = (x.cpu() + 1.0) / 2.0
     p_ref = gu.psnr(out, torch.as_tensor(fx["img"]))
@@ -164,10 +167,10 @@ def test_c1_toy_ddpm_ddim_eta(engine, report):
     # pinned here: x_T exact, every extracted eps within the bound above, finite output; the image-space
     # PSNR is reported, and held to a floor that catches gross breakage only. The well-conditioned
     # variants (sample_type='ddpm' below, the latent SD chain above) are held to tight bounds.
-    assert p_ref > 9.0, p_ref
-    assert p_img > 9.0, p_img
+    assert p_ref > (15.0 if FMT == 1.0 else 9.0), p_ref  # measured 21.4 dB (fp16)
+    assert p_img > (15.0 if FMT == 1.0 else 9.0), p_img
 
 
 def test_c1_toy_ddpm_ddpm_type(engine, report):
     p_ref, _ = _c1(engine, report, "c1_toy_ddpm_ddpmtype", 20, None, "ddpm")
-    assert p_ref > 30.0, p_ref
+    assert p_ref > (60.0 if FMT == 1.0 else 30.0), p_ref  # measured 99.5 dB (fp16)
