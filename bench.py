@@ -74,6 +74,22 @@ def cpu_baseline(eng, un, vn, seed=0):
                       % (t_u1, t_u2, t_e, t_d, per_img)}
 
 
+def pmc_traffic_per_launch():
+    """HBM-side bytes per k_conv_gemm launch from the committed rocprofv3 PMC passes (profiles/README.md):
+    FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over one U-Net forward at B'=4 (encode) and B'=8 (CFG
+    decode); a C2 step launches both forward types equally often. None when the summaries are absent."""
+    vals = []
+    for b in (4, 8):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                            "r1_conv_gemm_traffic_unet_b%d.json" % b)
+        try:
+            with open(path) as fh:
+                vals.append(float(json.load(fh)["bytes_per_launch"]))
+        except (OSError, KeyError, ValueError):
+            return None
+    return sum(vals) / len(vals)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,6 +171,7 @@ def main():
         n_launch, k_ms, k_flops = eng.prof_collect()
         eng.prof_enable(False)
         ach = k_flops / (k_ms * 1e-3) / 1e12
+        traffic = pmc_traffic_per_launch()
         res = {
             "metric": "images/sec, SD-v1.4 512px CycleDiffusion 100+100 steps, 1/2/4/8 MI355X", "value": ips,
             "unit": "images/s",
@@ -167,7 +184,8 @@ def main():
                        "weights": model.gan_wrapper.weights_origin, "flop_per_image": F_IMG},
             "roofline": {"bound": "mfma", "kernel": "k_conv_gemm (all tile instantiations)",
                          "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS,
-                         "traffic": None, "launches_per_step": n_launch, "kernel_ms_per_step": k_ms,
+                         "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC, profiles/)",
+                         "launches_per_step": n_launch, "kernel_ms_per_step": k_ms,
                          "algorithmic_tflop_per_step": k_flops / 1e12,
                          "whole_path_frac": ips * F_IMG / 1e12 / (world * PEAK_TFLOPS)},
         }
