@@ -1,0 +1,122 @@
+"""Parity at BASELINE.json's full sizes (C2: SD-v1.4 shapes, latent 64x64, ctx 77x768; KL-f8 VAE at 512x512).
+
+Direct comparisons against the CPU oracle where it finishes in seconds (single network evaluations), and
+size-independent properties for the sampler loops: encode -> decode with the same text closes the cycle,
+a sample's result does not depend on which batch it travelled in (the sharding contract of SURVEY.md
+§8(e)), and repeated runs are bit-identical.
+"""
+import pytest
+import torch
+
+import cycle_diffusion_amd as cda
+from cycle_diffusion_amd import _ffi, schedule
+from oracle import nets
+
+pytestmark = pytest.mark.gpu
+
+FMT = 1.0 if _ffi.load_library().cd_act_format() == 1 else 8.0
+
+
+def _rel(got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    d = (got - ref).abs()
+    return d.max().item() / (ref.abs().max().item() + 1e-12), d.mean().item() / (ref.abs().mean().item() + 1e-12)
+
+
+@pytest.fixture(scope="module")
+def sd_unet(engine):
+    net = engine.create_net(cda.sd_v1_unet_desc())
+    sd = nets.synth_state_dict(engine.net_params(net), 0)
+    n, first = engine.load_state_dict(net, sd)
+    assert n == 0, first
+    return net, sd
+
+
+@pytest.fixture(scope="module")
+def sd_vae(engine):
+    net = engine.create_net(cda.kl_f8_vae_desc())
+    sd = nets.synth_state_dict(engine.net_params(net), 1)
+    n, first = engine.load_state_dict(net, sd)
+    assert n == 0, first
+    return net, sd
+
+
+def _inputs(B, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    x0 = torch.randn(B, 4, 64, 64, generator=g)
+    c = torch.randn(B, 77, 768, generator=g)
+    uc = torch.randn(B, 77, 768, generator=g)
+    return x0, c, uc
+
+
+def test_sd_unet_forward_full_size_vs_oracle(engine, report, sd_unet):
+    """One eps-hat evaluation of the 860 M-parameter U-Net (openaimodel.py:710-742) at the C2 shapes."""
+    net, sd = sd_unet
+    cfg = nets.OpenAIUNetCfg(in_channels=4, out_channels=4, model_channels=320, num_res_blocks=2,
+                             channel_mult=(1, 2, 4, 4), attn_ds=(4, 2, 1), num_heads=8,
+                             use_spatial_transformer=True, context_dim=768)
+    x, c, _ = _inputs(2)
+    t = torch.tensor([981, 11])
+    with torch.no_grad():
+        ref = nets.openai_unet(sd, cfg, x, t, c)
+    y = engine.unet_forward(net, x.cuda(), t.float().cuda(), c.cuda())
+    rmax, rmean = _rel(y, ref)
+    report.add("fullsize/sd_unet", rel_to_max=rmax, mean_rel=rmean)
+    assert rmax < 8e-3 * FMT and rmean < 8e-3 * FMT, (rmax, rmean)
+
+
+def test_kl_f8_vae_full_size_vs_oracle(engine, report, sd_vae):
+    """AutoencoderKL encode (posterior mean) and decode at 512x512 (autoencoder.py:324-333)."""
+    net, sd = sd_vae
+    cfg = nets.VAECfg(ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2)
+    img = torch.rand((1, 3, 512, 512), generator=torch.Generator().manual_seed(4)) * 2 - 1
+    with torch.no_grad():
+        mom = nets.vae_encode_moments(sd, cfg, img)
+        zz = mom[:, :4] * 0.5
+        dec = nets.vae_decode(sd, cfg, zz)
+    z = engine.vae_encode(net, img.cuda(), sample=False, scale=1.0)
+    r1 = _rel(z, mom[:, :4])
+    d = engine.vae_decode(net, zz.cuda(), scale=1.0)
+    r2 = _rel(d, dec)
+    report.add("fullsize/kl_f8_vae", enc_rel_to_max=r1[0], enc_mean_rel=r1[1], dec_rel_to_max=r2[0], dec_mean_rel=r2[1])
+    assert r1[0] < 1e-2 * FMT and r1[1] < 1e-2 * FMT, r1
+    assert r2[0] < 1e-2 * FMT and r2[1] < 1e-2 * FMT, r2
+
+
+def test_c2_cycle_batch_independence_determinism(engine, report, sd_unet):
+    """DPM-Encoder + DDIM decode at the C2 latent size, 20 steps: (1) same-text decode returns x0, (2) sample 0
+    encoded alone equals sample 0 encoded in a batch of 2 up to 16-bit rounding (tile / split-K choices follow
+    the GEMM row count, so the fp32 summation order may differ, nothing else), (3) two identical calls are
+    bit-identical."""
+    net, _ = sd_unet
+    x0, c, uc = _inputs(2, seed=9)
+    K = 20
+    sch = schedule.DDIMSchedule(schedule.latent_alphas_cumprod(), K, 0.1)
+    g = torch.Generator().manual_seed(3)
+    noise = torch.randn(K, 2, 4, 64, 64, generator=g)
+    enc = lambda xs, cs, ns: engine.dpm_encode(net, _ffi.CD_SCHED_DDIM, xs.cuda(), sch.coef_encode(), ctx_c=cs.cuda(),
+                                               guidance=1.0, noise=ns.cuda())
+    z = enc(x0, c, noise)
+    assert z.shape == (2, K + 1, 4, 64, 64) and torch.isfinite(z).all()
+    z_again = enc(x0, c, noise)
+    assert torch.equal(z, z_again)
+    x_same = engine.ddim_decode(net, _ffi.CD_SCHED_DDIM, z, sch.coef_decode(), ctx_c=c.cuda(), guidance=1.0)
+    cyc = (x_same.cpu() - x0).abs().max().item()
+    cyc_rms = (x_same.cpu() - x0).pow(2).mean().sqrt().item()
+    z_one = enc(x0[:1], c[:1], noise[:, :1])
+    # x_T is scheduler-only math: exact; the eps slots carry the network's rounding divided by sigma
+    assert torch.equal(z_one[:, 0], z[:1, 0])
+    eps_scale = z[:1, 1:].abs().max().item()
+    bdiff = (z_one[:, 1:] - z[:1, 1:]).abs().max().item() / eps_scale
+    # CFG decode towards another text: finite, and different from the source
+    x_tgt = engine.ddim_decode(net, _ffi.CD_SCHED_DDIM, z, sch.coef_decode(), ctx_c=c.flip(0).cuda(), ctx_uc=uc.cuda(),
+                               guidance=3.0)
+    report.add("fullsize/c2_cycle", cycle_maxabs=cyc, cycle_rms=cyc_rms, batch_rel=bdiff,
+               tgt_delta=float((x_tgt.cpu() - x0).abs().mean()))
+    # The decode pass recomputes x_{t-1} = A + sigma*((x_next - A)/sigma): one fp32 rounding away from the
+    # encoder's x_next, which flips a handful of 16-bit input roundings per step; a RANDOM-INIT 860 M-parameter
+    # U-Net amplifies that ~100x over the chain (the fp32 reference amplifies its own 1e-7 rounding to 1.6e-5,
+    # SURVEY.md 8c). Measured on MI355X: max 3.1e-2, i.e. 3 % of the unit-variance latent; bound = 3x.
+    assert cyc < 0.1 * FMT, cyc
+    assert bdiff < 2e-2 * FMT, bdiff
+    assert torch.isfinite(x_tgt).all() and (x_tgt.cpu() - x0).abs().mean() > 1e-3
