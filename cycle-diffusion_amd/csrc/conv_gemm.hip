@@ -8,13 +8,15 @@
 // the K loop and nearest-x2 upsampling (openaimodel.py:115) is folded into the gather address.
 //
 // Structure (CDNA4): 4 or 8 waves per workgroup; BMxBN tile, BK-deep K steps; both operands are
-// staged HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip) into an NSTAGE-deep LDS
-// ring; the wait for a tile is a COUNTED s_waitcnt vmcnt(N) (younger tiles stay in flight across the
-// single workgroup barrier per K step); LDS rows are XOR-swizzled on the *source* side so
+// staged HBM/L2 -> LDS with `buffer_load_dwordx4 ... offen lds` (no VGPR round trip) through buffer
+// descriptors - padding taps and rows beyond M carry an out-of-range offset and arrive as zeros - into an
+// NSTAGE-deep LDS ring; the wait for a tile is a COUNTED s_waitcnt vmcnt(N) (younger tiles stay in flight
+// across the single workgroup barrier per K step); LDS rows are XOR-swizzled on the *source* side so
 // ds_read_b128 fragment reads are conflict free; accumulators go through LDS in the epilogue so
-// global stores are 16 B per lane with bias / time-embedding / residual / SiLU / GELU / GEGLU fused.
-// Per-element reduction order is k-ascending for every tile configuration, so results do not
-// depend on which configuration (or batch size) is chosen.
+// global stores are 16 B per lane with bias / time-embedding / residual / SiLU / GELU / GEGLU and the
+// consumer's GroupNorm statistics fused. Deep-K layers with few output tiles run split-K (gridDim.y).
+// Per-element reduction order is k-ascending for every tile configuration, so results do not depend on
+// the configuration; a split factor > 1 sums the K ranges in range order (fixed for a given shape).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
