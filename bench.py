@@ -97,17 +97,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4, help="image triplets per GPU per step (README.md:153)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group even at world size 1 (exercises the gather path on a 1-GPU box)")
     a = ap.parse_args()
 
     torch.set_num_threads(host_cores())  # host-side weight synthesis / oracle: stay inside the CPU quota
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 or world > 1:
+    if a.gpus > 1 or world > 1 or a.force_dist:
         assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
@@ -140,7 +143,7 @@ def main():
         return gather_outputs((orig, img), loss)  # one all-gather per eval step (trainer.py:833)
 
     def sync():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -152,7 +155,7 @@ def main():
         out = step()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -192,7 +195,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(eng, model.gan_wrapper.unet, model.gan_wrapper.vae)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     return res

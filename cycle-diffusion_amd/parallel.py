@@ -15,7 +15,7 @@ def shard_range(n_items, world_size, rank):
 
 
 def _concat(t):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return t
     t = t.contiguous()
     outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
@@ -26,7 +26,7 @@ def _concat(t):
 def gather_outputs(tensors, loss=None):
     """nested tuple of per-rank tensors -> same structure concatenated along dim 0 in rank order."""
     if isinstance(tensors, (tuple, list)):
-        out = type(tensors)(gather_outputs(t)[0] if False else _gather_nested(t) for t in tensors)
+        out = type(tensors)(_gather_nested(t) for t in tensors)
     else:
         out = _concat(tensors)
     return out, (_concat(loss) if loss is not None else None)
