@@ -120,3 +120,46 @@ def test_c2_cycle_batch_independence_determinism(engine, report, sd_unet):
     assert cyc < 0.1 * FMT, cyc
     assert bdiff < 2e-2 * FMT, bdiff
     assert torch.isfinite(x_tgt).all() and (x_tgt.cpu() - x0).abs().mean() > 1e-3
+
+
+def _fresh(engine, desc, seed):
+    net = engine.create_net(desc)
+    sd = nets.synth_state_dict(engine.net_params(net), seed)
+    n, first = engine.load_state_dict(net, sd)
+    assert n == 0, first
+    return net, sd
+
+
+def test_afhq_iddpm_forward_full_size_vs_oracle(engine, report):
+    """BASELINE config 5's network: improved-DDPM U-Net for AFHQ 256x256 (unet.py:401-668; FiLM ResBlocks,
+    resblock up/down, 64-channel legacy attention heads at 16x16 and in the middle, 6 output channels)."""
+    net, sd = _fresh(engine, cda.afhq_iddpm_desc(256), 2)
+    cfg = nets.OpenAIUNetCfg(in_channels=3, out_channels=6, model_channels=128, num_res_blocks=1,
+                             channel_mult=(1, 1, 2, 2, 4, 4), attn_ds=(16,), num_heads=4, num_head_channels=64,
+                             use_scale_shift_norm=True, resblock_updown=True)
+    x = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(8))
+    t = torch.tensor([640.0])
+    with torch.no_grad():
+        ref = nets.openai_unet(sd, cfg, x, t)
+    y = engine.unet_forward(net, x.cuda(), t.cuda())
+    rmax, rmean = _rel(y, ref)
+    report.add("fullsize/afhq_iddpm", rel_to_max=rmax, mean_rel=rmean)
+    assert rmax < 8e-3 * FMT and rmean < 8e-3 * FMT, (rmax, rmean)
+
+
+def test_ldm_text_unet_forward_full_size_vs_oracle(engine, report):
+    """BASELINE config 3's network: LDM text2img-large U-Net (context dim 1280) at the 256x256 latent size 32x32."""
+    net, sd = _fresh(engine, cda.ldm_text_unet_desc(32), 3)
+    cfg = nets.OpenAIUNetCfg(in_channels=4, out_channels=4, model_channels=320, num_res_blocks=2,
+                             channel_mult=(1, 2, 4, 4), attn_ds=(4, 2, 1), num_heads=8,
+                             use_spatial_transformer=True, context_dim=1280)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 4, 32, 32, generator=g)
+    c = torch.randn(2, 77, 1280, generator=g)
+    t = torch.tensor([901.0, 101.0])
+    with torch.no_grad():
+        ref = nets.openai_unet(sd, cfg, x, t, c)
+    y = engine.unet_forward(net, x.cuda(), t.cuda(), c.cuda())
+    rmax, rmean = _rel(y, ref)
+    report.add("fullsize/ldm_text_unet", rel_to_max=rmax, mean_rel=rmean)
+    assert rmax < 8e-3 * FMT and rmean < 8e-3 * FMT, (rmax, rmean)
