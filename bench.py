@@ -15,6 +15,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import torch
@@ -97,6 +98,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4, help="image triplets per GPU per step (README.md:153)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=4,
+                    help="batches in flight per GPU: independent engine replicas (own HIP stream, workspace and "
+                         "weights) driven by host threads; every step is still one batch of --batch triplets")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even at world size 1 (exercises the gather path on a 1-GPU box)")
     a = ap.parse_args()
@@ -123,8 +127,17 @@ def main():
 
     os.environ["LOCAL_RANK"] = str(local)
     args = get_config("experiments/bench_sd_c2.cfg", config_root=os.path.join(ROOT, "config"))
-    torch.manual_seed(0)  # same weights on every rank (main.py:66)
-    model = get_model(args.model.name)(args).eval()
+    # A single stream of these kernels leaves the GPU under-occupied (most launches are wait-bound at 1-3
+    # workgroups per CU): two independent batches in flight on two HIP streams raise whole-GPU
+    # throughput ~1.4x. Replica r owns stream r, its own engine (workspace, split-K scratch) and weights.
+    n_rep = max(1, a.in_flight)
+    replicas = []
+    for r in range(n_rep):
+        st = torch.cuda.Stream(device=dev) if n_rep > 1 else torch.cuda.current_stream(dev)
+        with torch.cuda.stream(st):
+            torch.manual_seed(0)  # same weights on every rank and replica (main.py:66)
+            replicas.append((st, get_model(args.model.name)(args).eval()))
+    model = replicas[0][1]
     eng = model.gan_wrapper.engine
 
     # synthetic batch: global batch = B * world, rank r takes its contiguous slice (ShardSampler, trainer.py:288-293)
@@ -137,22 +150,56 @@ def main():
     tgt = ["target prompt %d" % i for i in range(lo, hi)]
     torch.manual_seed(4 + rank)  # per-rank noise streams
 
-    def step():
-        with torch.no_grad():
-            (orig, img), loss, _ = model(sample_id=sample_id, original_image=images, encode_text=src, decode_text=tgt)
+    def compute(r, res):
+        st, m = replicas[r]
+        torch.cuda.set_device(dev)  # the current device is per host thread
+        with torch.cuda.stream(st), torch.no_grad():
+            res[r] = m(sample_id=sample_id, original_image=images, encode_text=src, decode_text=tgt)
+
+    def gather(r, res):
+        (orig, img), loss, _ = res[r]
+        torch.cuda.current_stream(dev).wait_stream(replicas[r][0])
         return gather_outputs((orig, img), loss)  # one all-gather per eval step (trainer.py:833)
+
+    def step(r=0):
+        res = {}
+        compute(r, res)
+        return gather(r, res)
+
+    def run_steps(n):
+        """n steps, up to n_rep of them in flight: one host thread per replica computes, then the main thread
+        does that round's all-gathers in step order (every rank issues its collectives in the same order)."""
+        out = None
+        done = 0
+        while done < n:
+            k = min(n_rep, n - done)
+            res = {}
+            if k == 1:
+                compute(0, res)
+            else:
+                ths = [threading.Thread(target=compute, args=(r, res)) for r in range(k)]
+                for t in ths:
+                    t.start()
+                for t in ths:
+                    t.join()
+            for r in range(k):
+                assert r in res, "replica %d failed" % r
+                out = gather(r, res)
+            done += k
+        return out
 
     def sync():
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
-        step()
+    for _ in range(a.warmup):  # replica by replica: the first one tunes the GEMM table, the others reuse it
+        for r in range(n_rep):
+            step(r)
+            torch.cuda.synchronize(dev)
     sync()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
+    out = run_steps(a.steps)
     sync()
     dt = time.perf_counter() - t0
     if dist.is_initialized():
@@ -184,6 +231,7 @@ def main():
             "config": {"workload": "C2: Stable-Diffusion-v1.4-shaped U-Net + KL-f8 VAE, 512x512, custom_steps=99 "
                                    "white_box_steps=100 eta=0.1 skip 0, 1 trial, encoder scale 1, decoder CFG 3",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "batches_in_flight_per_gpu": n_rep,
                        "weights": model.gan_wrapper.weights_origin, "flop_per_image": F_IMG},
             "roofline": {"bound": "mfma", "kernel": "k_conv_gemm (all tile instantiations)",
                          "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS,

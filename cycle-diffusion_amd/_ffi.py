@@ -97,7 +97,8 @@ def load_library(build_if_missing=True):
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         mod.build()
-    lib = C.CDLL(LIB_PATH)
+    # CYCLEDIFF_LIB: A/B timing of two builds of the SAME ABI on one box (scripts/); never a CPU fallback
+    lib = C.CDLL(os.environ.get("CYCLEDIFF_LIB") or LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # raises AttributeError if the symbol is not exported
         fn.argtypes = args

@@ -19,6 +19,7 @@ struct cd_engine {
   std::vector<ParamStore*> op_stores;  // storage behind cd_op_pack_conv
   ParamStore op_params;
   std::unique_ptr<KernelProfiler> prof;
+  SplitKWorkspace splitk;  // split-K partial tiles + arrival counters of THIS engine's stream (conv_gemm.hip)
   Ctx ctx() {
     Ctx c; c.st = st; c.arena = &arena; c.zeros = zeros; c.gn_partial = gn_partial;
     c.gn_partial_floats = gn_partial_floats;
@@ -27,6 +28,15 @@ struct cd_engine {
 };
 
 static thread_local std::string g_err;
+
+// Engines are independent (own stream, arena, workspaces): several may run concurrently from different host
+// threads - that is how bench.py keeps two batches in flight per GPU. The calling thread binds the kernel
+// layer's per-stream state to its engine at every API entry.
+static void enter_engine(cd_engine* h) {
+  if (!h) return;
+  g_conv_splitk = h->splitk;
+  g_conv_prof = (h->prof && h->prof->enabled) ? h->prof.get() : nullptr;
+}
 
 #define CD_API_BEGIN try {
 #define CD_API_END                                  \
@@ -81,14 +91,12 @@ int cd_engine_create(void* hip_stream, size_t workspace_bytes, cd_handle* out) {
       g_conv_tuner.enabled = true;
     }
   }
-  if (!g_conv_splitk.scratch) {  // split-K partial tiles + arrival counters (conv_gemm.hip)
-    g_conv_splitk.scratch_bytes = (size_t)256 << 20;
-    g_conv_splitk.nflags = 1 << 16;
-    HIP_CHECK(hipMalloc((void**)&g_conv_splitk.scratch, g_conv_splitk.scratch_bytes));
-    HIP_CHECK(hipMalloc((void**)&g_conv_splitk.flags, g_conv_splitk.nflags * sizeof(int)));
-    HIP_CHECK(hipMemset(g_conv_splitk.flags, 0, g_conv_splitk.nflags * sizeof(int)));
-    HIP_CHECK(hipDeviceSynchronize());
-  }
+  h->splitk.scratch_bytes = (size_t)256 << 20;
+  h->splitk.nflags = 1 << 16;
+  HIP_CHECK(hipMalloc((void**)&h->splitk.scratch, h->splitk.scratch_bytes));
+  HIP_CHECK(hipMalloc((void**)&h->splitk.flags, h->splitk.nflags * sizeof(int)));
+  HIP_CHECK(hipMemset(h->splitk.flags, 0, h->splitk.nflags * sizeof(int)));
+  HIP_CHECK(hipDeviceSynchronize());
   h->gn_partial_floats = (size_t)1 << 20;
   HIP_CHECK(hipMalloc((void**)&h->gn_partial, h->gn_partial_floats * sizeof(float)));
   *out = h.release();
@@ -97,9 +105,13 @@ int cd_engine_create(void* hip_stream, size_t workspace_bytes, cd_handle* out) {
 
 int cd_engine_destroy(cd_handle h) {
   CD_API_BEGIN
+  enter_engine(h);
   if (h) {
     (void)hipStreamSynchronize(h->st);
     if (g_conv_prof == h->prof.get()) g_conv_prof = nullptr;
+    if (g_conv_splitk.scratch == h->splitk.scratch) g_conv_splitk = SplitKWorkspace();
+    if (h->splitk.scratch) (void)hipFree(h->splitk.scratch);
+    if (h->splitk.flags) (void)hipFree(h->splitk.flags);
     if (h->zeros) (void)hipFree(h->zeros);
     if (h->gn_partial) (void)hipFree(h->gn_partial);
     delete h;
@@ -109,6 +121,7 @@ int cd_engine_destroy(cd_handle h) {
 
 int cd_prof_enable(cd_handle h, int on) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h, "null handle");
   if (!h->prof) h->prof.reset(new KernelProfiler());
   h->prof->enabled = on != 0;
@@ -122,6 +135,7 @@ int cd_prof_enable(cd_handle h, int on) {
 
 int cd_prof_collect(cd_handle h, int* launches, double* total_ms, double* total_flops) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && h->prof && launches && total_ms && total_flops, "profiler not enabled");
   HIP_CHECK(hipStreamSynchronize(h->st));
   h->prof->collect(launches, total_ms, total_flops);
@@ -130,6 +144,7 @@ int cd_prof_collect(cd_handle h, int* launches, double* total_ms, double* total_
 
 int cd_engine_workspace_high_water(cd_handle h, size_t* bytes) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && bytes, "null argument");
   *bytes = h->arena.high_water();
   CD_API_END
@@ -137,6 +152,7 @@ int cd_engine_workspace_high_water(cd_handle h, size_t* bytes) {
 
 int cd_net_create(cd_handle h, const cd_net_desc* d, int* net_id) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && d && net_id, "null argument");
   std::unique_ptr<Net> n;
   switch (d->kind) {
@@ -152,6 +168,7 @@ int cd_net_create(cd_handle h, const cd_net_desc* d, int* net_id) {
 
 int cd_net_param_count(cd_handle h, int net, int* n) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && n && net >= 0 && net < (int)h->nets.size(), "bad argument");
   *n = (int)h->nets[net]->params.decls().size();
   CD_API_END
@@ -159,6 +176,7 @@ int cd_net_param_count(cd_handle h, int net, int* n) {
 
 int cd_net_param_info(cd_handle h, int net, int index, char* name, int name_cap, int* ndim, int64_t shape[4]) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && net >= 0 && net < (int)h->nets.size(), "bad net id");
   auto& ds = h->nets[net]->params.decls();
   CD_CHECK(index >= 0 && index < (int)ds.size(), "bad parameter index");
@@ -172,6 +190,7 @@ int cd_net_param_info(cd_handle h, int net, int index, char* name, int name_cap,
 int cd_net_load_param(cd_handle h, int net, const char* name, const float* data_host, int ndim,
                       const int64_t* shape) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && name && data_host && shape && net >= 0 && net < (int)h->nets.size(), "bad argument");
   h->nets[net]->params.load(h->st, name, data_host, ndim, shape);
   CD_API_END
@@ -179,6 +198,7 @@ int cd_net_load_param(cd_handle h, int net, const char* name, const float* data_
 
 int cd_net_missing_params(cd_handle h, int net, int* n_missing, char* first_name, int name_cap) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && n_missing && net >= 0 && net < (int)h->nets.size(), "bad argument");
   std::string first;
   *n_missing = h->nets[net]->params.missing(&first);
@@ -276,6 +296,7 @@ extern "C" {
 int cd_unet_forward(cd_handle h, int net, const float* x, const float* t, const float* ctx, int B,
                     int ctx_len, float* eps_out) {
   CD_API_BEGIN
+  enter_engine(h);
   UNet* u = get_unet(h, net);
   CD_CHECK(x && t && eps_out && B > 0, "bad argument");
   const size_t mk = h->arena.mark();
@@ -300,6 +321,7 @@ int cd_unet_forward(cd_handle h, int net, const float* x, const float* t, const 
 int cd_vae_encode(cd_handle h, int net, const float* img, const float* noise, uint64_t seed, int B, int R,
                   int sample, float scale, float* z0) {
   CD_API_BEGIN
+  enter_engine(h);
   VAE* v = get_vae(h, net);
   CD_CHECK(img && z0 && B > 0 && R % v->factor == 0, "bad argument");
   const size_t mk = h->arena.mark();
@@ -318,6 +340,7 @@ int cd_vae_encode(cd_handle h, int net, const float* img, const float* noise, ui
 int cd_vae_decode(cd_handle h, int net, const float* z0, int B, int hlat, float scale, float out_mul,
                   float out_add, float* img) {
   CD_API_BEGIN
+  enter_engine(h);
   VAE* v = get_vae(h, net);
   CD_CHECK(z0 && img && B > 0 && hlat > 0, "bad argument");
   const size_t mk = h->arena.mark();
@@ -337,6 +360,7 @@ int cd_dpm_encode(cd_handle h, int net, int sched_kind, const float* x0, const f
                   const cd_step_coef* coef_host, const float* noise, uint64_t seed, int last_uses_x0,
                   float* z_out) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && x0 && coef_host && z_out && B > 0 && K > 0, "bad argument");
   const size_t mk = h->arena.mark();
   SamplerState s = setup_sampler(h, net, ctx_c, ctx_uc, ctx_len, guidance, B);
@@ -361,6 +385,7 @@ int cd_ddim_decode(cd_handle h, int net, int sched_kind, const float* z, int z_s
                    const float* ctx_c, const float* ctx_uc, int ctx_len, float guidance, int B, int K,
                    const cd_step_coef* coef_host, const float* noise_tail, uint64_t seed, float* x_out) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && z && coef_host && x_out && B > 0 && K > 0 && n_eps <= z_slots - 1, "bad argument");
   const size_t mk = h->arena.mark();
   SamplerState s = setup_sampler(h, net, ctx_c, ctx_uc, ctx_len, guidance, B);
@@ -386,6 +411,7 @@ int cd_ddim_decode(cd_handle h, int net, int sched_kind, const float* z, int z_s
 int cd_pix_refine(cd_handle h, int net, int sched_kind, float* x, int B, int R, const cd_step_coef* coef_host,
                   const float* noise, uint64_t seed) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && x && coef_host && B > 0 && R > 0, "bad argument");
   const size_t mk = h->arena.mark();
   SamplerState s = setup_sampler(h, net, nullptr, nullptr, 0, 1.f, B);
@@ -408,6 +434,7 @@ int cd_pix_refine(cd_handle h, int net, int sched_kind, float* x, int B, int R, 
 int cd_op_pack_conv_weight(cd_handle h, const float* w_host, int N, int Cin, int KH, int KW, int geglu,
                            void** packed_dev, int* Npad, int* Cpad) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && w_host && packed_dev, "bad argument");
   static int counter = 0;
   ConvW* c = h->op_params.new_conv(N, Cin, KH, KW, false, geglu != 0);
@@ -427,6 +454,7 @@ int cd_op_conv2d(cd_handle h, const float* x0, int C0, const float* x1, int C1, 
                  const void* packed_w, int N, int KH, int KW, int stride, int pad, int asym_pad, int up,
                  const float* bias, const float* rowvec, const float* resid, int act, int tile, float* y) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && x0 && packed_w && y, "bad argument");
   const size_t mk = h->arena.mark();
   Ctx c = h->ctx();
@@ -463,6 +491,7 @@ int cd_op_conv2d(cd_handle h, const float* x0, int C0, const float* x1, int C1, 
 int cd_op_groupnorm(cd_handle h, const float* x, int B, int C, int H, int W, int G, float eps,
                     const float* gamma, const float* beta, const float* film, int silu, float* y) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && x && y && G == 32, "bad argument (G must be 32)");
   const size_t mk = h->arena.mark();
   Ctx c = h->ctx();
@@ -478,6 +507,7 @@ int cd_op_groupnorm(cd_handle h, const float* x, int B, int C, int H, int W, int
 int cd_op_layernorm(cd_handle h, const float* x, int rows, int C, const float* gamma, const float* beta,
                     float eps, float* y) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && x && y, "bad argument");
   const size_t mk = h->arena.mark();
   bf16_t* a = (bf16_t*)h->arena.alloc((size_t)rows * C * 2);
@@ -492,6 +522,7 @@ int cd_op_layernorm(cd_handle h, const float* x, int rows, int C, const float* g
 int cd_op_attention(cd_handle h, const float* q, const float* k, const float* v, int B, int H, int Tq,
                     int Tk, int D, float scale, int use_transpose_kernel, float* o) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && q && k && v && o, "bad argument");
   (void)use_transpose_kernel;
   const size_t mk = h->arena.mark();
@@ -517,6 +548,7 @@ int cd_op_attention(cd_handle h, const float* q, const float* k, const float* v,
 
 int cd_op_softmax_rows(cd_handle h, const float* s, int64_t rows, int cols, float* p) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && s && p, "bad argument");
   const size_t mk = h->arena.mark();
   bf16_t* pb = (bf16_t*)h->arena.alloc((size_t)rows * cols * 2);
@@ -528,6 +560,7 @@ int cd_op_softmax_rows(cd_handle h, const float* s, int64_t rows, int cols, floa
 
 int cd_op_timestep_embedding(cd_handle h, const float* t, int B, int dim, int mode, float* out) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && t && out, "bad argument");
   launch_timestep_embedding(h->st, nullptr, nullptr, 0, t, out, B, dim, mode);
   CD_API_END
@@ -537,6 +570,7 @@ int cd_op_sched_step(cd_handle h, int mode, int sched_kind, const cd_step_coef* 
                      float* xt, const float* eps_hat, int cfg, float guidance, const float* noise,
                      const float* eps_in, int is_last, int B, int C, int HW, float* z_slot) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && coef_host && xt, "bad argument");
   const size_t mk = h->arena.mark();
   StepCoef* tab = upload_coef(h, coef_host, 1);
@@ -610,6 +644,7 @@ __global__ void k_fill_hash16(bf16_t* p, int64_t n, uint32_t seed, float scale) 
 extern "C" int cd_op_bench_conv(cd_handle h, int B, int H, int W, int C0, int C1, int N, int k, int stride,
                                 int up, int act, int tile, int iters, float* ms_out) {
   CD_API_BEGIN
+  enter_engine(h);
   CD_CHECK(h && ms_out && iters > 0, "bad argument");
   const size_t mk = h->arena.mark();
   Ctx c = h->ctx();
@@ -648,6 +683,7 @@ extern "C" int cd_op_bench_conv(cd_handle h, int B, int H, int W, int C0, int C1
 
 extern "C" int cd_op_probe(cd_handle h, int which, const void* in, void* out, size_t n) {
   CD_API_BEGIN
+  enter_engine(h);
   (void)in;
   CD_CHECK(h && out, "bad argument");
   if (which == 0) {

@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
 
 #include "common.h"
@@ -52,7 +53,7 @@ struct TileCfg {
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   static constexpr int EPI_BYTES = NW * TM * EPI_LD * 4;
   static constexpr int LDS_BYTES = STAGE_BYTES * NSTAGE > EPI_BYTES ? STAGE_BYTES * NSTAGE : EPI_BYTES;
-  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");
   static_assert(A_IPW >= 1 && B_IPW >= 1, "tile too small for the wave count");
   static_assert(A_IPW * RPI * NW == BM && B_IPW * RPI * NW == BN, "tile rows must split evenly over waves");
   static_assert(MT >= 1 && NT >= 1, "wave tile");
@@ -513,11 +514,13 @@ const CfgInfo kCfgs[] = {
     {15, 64, 64, 32, "64x64 w2x2 s8"},
     {16, 128, 64, 64, "128x64 w4x1 s6"},
     {17, 64, 128, 64, "64x128 w2x2 s6"},
+    {18, 256, 128, 32, "256x128 w4x4 s3"},
+    {19, 256, 128, 64, "256x128 w8x2 s3"},
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 }  // namespace gemm_detail
-SplitKWorkspace g_conv_splitk;
+thread_local SplitKWorkspace g_conv_splitk;
 namespace gemm_detail {
 
 template <int BK>
@@ -546,6 +549,14 @@ void dispatch(hipStream_t st, const ConvGemmParams& p, int id) {
     case 15: launch_cfg<64, 64, BK, 2, 2, 8>(st, p); break;
     case 16: launch_cfg<128, 64, BK, 4, 1, 6>(st, p); break;
     case 17: launch_cfg<64, 128, BK, 2, 2, 6>(st, p); break;
+    case 18:
+      if constexpr (BK == 64) launch_cfg<256, 128, 64, 4, 4, 3>(st, p);
+      else launch_cfg<256, 128, 32, 4, 2, 3>(st, p);  // 16 waves need >= 16 row groups per B tile
+      break;
+    case 19:
+      if constexpr (BK == 64) launch_cfg<256, 128, 64, 8, 2, 3>(st, p);
+      else launch_cfg<256, 128, 32, 4, 2, 3>(st, p);
+      break;
     default: CD_CHECK(false, "conv_gemm: unknown tile configuration %d", id);
   }
 }
@@ -567,7 +578,7 @@ using namespace gemm_detail;
 
 const char* conv_gemm_last_config() { return g_last_cfg; }
 
-KernelProfiler* g_conv_prof = nullptr;
+thread_local KernelProfiler* g_conv_prof = nullptr;
 
 void KernelProfiler::next_pair(hipEvent_t* a, hipEvent_t* b, double fl, const std::string& what) {
   labels.push_back(what);
@@ -655,7 +666,10 @@ void tune_cache_append(const ShapeKey& k, int val) {
   }
 }
 
+std::mutex g_tune_mu;  // engines on different host threads share one table; tuning itself is serialised
+
 int tuned_config(hipStream_t st, const ConvGemmParams& p, bool k64) {
+  std::lock_guard<std::mutex> lock(g_tune_mu);
   ConvTuner& tu = g_conv_tuner;
   if (!tu.enabled || !tu.scratch) return pick_config(p);
   const int nout = (p.act == ACT_GEGLU) ? p.N / 2 : p.N;

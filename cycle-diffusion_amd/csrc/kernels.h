@@ -91,7 +91,7 @@ struct SplitKWorkspace {
   int* flags = nullptr;  // zero-initialised arrival counters, one per output tile
   int nflags = 0;
 };
-extern SplitKWorkspace g_conv_splitk;
+extern thread_local SplitKWorkspace g_conv_splitk;  // the calling thread's engine (capi.hip enter_engine)
 void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p);
 const char* conv_gemm_last_config();
 int conv_gemm_num_configs();
@@ -113,7 +113,7 @@ struct KernelProfiler {
   void collect(int* launches, double* total_ms, double* total_flops);
   ~KernelProfiler();
 };
-extern KernelProfiler* g_conv_prof;
+extern thread_local KernelProfiler* g_conv_prof;
 
 // online tile-configuration autotuner of the implicit-GEMM kernel (conv_gemm.hip)
 struct ConvTuner {

@@ -10,12 +10,15 @@ _ENGINES = {}
 
 
 def get_engine(device=None):
-    """One engine (= one HIP stream + workspace) per device per process: one process per GPU."""
+    """One engine (= one HIP stream + workspace) per (device, current torch stream) per process: one process
+    per GPU, and normally one stream. A caller that wants several batches in flight on one GPU (bench.py) builds
+    each model replica under its own `torch.cuda.stream(s)`; every replica then gets its own engine bound to s."""
     if device is None:
         device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
-    key = str(torch.device(device))
+    dev = torch.device(device)
+    key = (str(dev), int(torch.cuda.current_stream(dev).cuda_stream))
     if key not in _ENGINES:
-        _ENGINES[key] = Engine(key)
+        _ENGINES[key] = Engine(str(dev))
     return _ENGINES[key]
 
 

@@ -10,8 +10,11 @@
  * Conventions: every pointer is a DEVICE pointer unless its name ends in _host; tensors at the
  * boundary are fp32, NCHW, contiguous (the reference's layout); all calls are asynchronous on the
  * engine's HIP stream; return value 0 = ok, non-zero = error with text in cd_last_error();
- * no exception crosses the ABI; one handle per rank / stream, not thread safe; the caller owns
- * every buffer it passes, the engine owns weights and workspace.
+ * no exception crosses the ABI; one handle per rank / stream. A handle is not thread safe (one host
+ * thread at a time), but DIFFERENT handles are independent - own stream, workspace, split-K scratch -
+ * and may be driven concurrently from different host threads on the same GPU (several batches in
+ * flight; tests/test_gpu_concurrency.py). The caller owns every buffer it passes, the engine owns
+ * weights and workspace.
  */
 #ifndef CYCLEDIFF_H
 #define CYCLEDIFF_H

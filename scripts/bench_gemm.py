@@ -49,7 +49,7 @@ if len(sys.argv) > 5 and sys.argv[5] == "half":  # spatial dims of the B'=B shap
 
 eng = cda.Engine("cuda:0", workspace_bytes=8 << 30)
 tot_ms, tot_fl, tot_best = 0.0, 0.0, 0.0
-TILES = [0] + ([int(t) for t in sys.argv[4].split(",")] if len(sys.argv) > 4 else list(range(1, 18)))
+TILES = [0] + ([int(t) for t in sys.argv[4].split(",")] if len(sys.argv) > 4 else list(range(1, 20)))
 print("shapes at B=%d; per-config TFLOP/s" % B)
 for name, hw, c0, c1, n, k, stride, up, act, calls in SHAPES:
     if only and only not in name:
@@ -58,7 +58,7 @@ for name, hw, c0, c1, n, k, stride, up, act, calls in SHAPES:
     fl = 2.0 * B * ho * ho * n * k * k * (c0 + c1)
     res = {}
     for tile in TILES:
-        if act == 3 and tile in (3, 8, 15):
+        if act == 3 and tile in (3, 8, 15, 18):
             continue
         ms = C.c_float()
         check(eng.lib.cd_op_bench_conv(eng.h, B, hw, hw, c0, c1, n, k, stride, up, act, tile, iters, C.byref(ms)))
