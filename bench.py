@@ -94,7 +94,7 @@ def pmc_traffic_per_launch():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4, help="image triplets per GPU per step (README.md:153)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

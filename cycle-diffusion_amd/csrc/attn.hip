@@ -146,13 +146,14 @@ __global__ __launch_bounds__(256, DV <= 96 ? 2 : 1) void k_attention(AttnParams 
       }
     }
     // ---- keys beyond Tk (last tile only), running max in raw units
-    if (key0 + KT > p.Tk) {
+    if (key0 + KT > p.Tk || p.causal) {
+      const int kmax = p.causal ? min(p.Tk - 1, q0 + qi) : p.Tk - 1;  // last visible key of this lane's query
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = key0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          s[kh][r] = key < p.Tk ? s[kh][r] : -INFINITY;
+          s[kh][r] = key <= kmax ? s[kh][r] : -INFINITY;
         }
     }
     // v_max3 directly: fmaxf() would first canonicalise every MFMA result (one extra VALU op each)

@@ -1,0 +1,142 @@
+// CLIP text transformer: the conditioning encoder of Stable Diffusion.
+//
+// Reference call site: FrozenCLIPEmbedder.forward (ldm/modules/encoders/modules.py:136-161) returns
+// `CLIPTextModel(...).last_hidden_state` of HF transformers (pinned 4.19.2 by the reference's environment;
+// not vendored) for "openai/clip-vit-large-patch14": 12 pre-LN layers, width 768, 12 heads, MLP 3072 with
+// quick-GELU, causal attention over 77 positions, final LayerNorm. Algorithm restated from
+// transformers/models/clip/modeling_clip.py (CLIPTextEmbeddings, CLIPAttention, CLIPMLP, CLIPEncoderLayer,
+// CLIPTextTransformer); weights are keyed by that module's state_dict names (the names found under
+// `cond_stage_model.transformer.` in an SD checkpoint).
+//
+// Every contraction runs on the implicit-GEMM kernel (conv_gemm.hip), attention on the flash kernel with its
+// causal mask (attn.hip); residual adds, biases and quick-GELU live in GEMM epilogues.
+#include "engine.h"
+
+namespace cd {
+
+namespace {
+
+struct ClipLayer {
+  LNW ln1, ln2;
+  ConvW *qk = nullptr, *v = nullptr, *o = nullptr, *fc1 = nullptr, *fc2 = nullptr;
+  float* vbias = nullptr;
+};
+
+LNW mk_ln(ParamStore& ps, const std::string& pfx, int C) {
+  LNW g; g.C = C;
+  g.g = ps.new_vec(C, 1.f); g.b = ps.new_vec(C, 0.f);
+  ps.vec(pfx + ".weight", g.g, C);
+  ps.vec(pfx + ".bias", g.b, C);
+  return g;
+}
+ConvW* mk_linear(ParamStore& ps, const std::string& pfx, int N, int K) {
+  ConvW* c = ps.new_conv(N, K, 1, 1, true);
+  ps.conv_weight(pfx + ".weight", c, 2);
+  ps.conv_bias(pfx + ".bias", c);
+  return c;
+}
+
+// V^T[b] = Wv . X[b]^T : weights as the A operand, tokens as the B operand -> [B][C][Tpad]
+void vt_gemm(Ctx& c, const ConvW& wv, const bf16_t* x, int ldx, int B, int T, int Tpad, bf16_t* vt) {
+  ConvGemmParams p;
+  p.src0 = wv.w; p.C0 = wv.Cpad; p.ld0 = wv.Cpad;
+  p.B = 1; p.Hs = wv.N; p.Ws = 1; p.Hin = wv.N; p.Win = 1; p.Hout = wv.N; p.Wout = 1;
+  p.M = wv.N;
+  p.wgt = x; p.Ktot = wv.Cpad; p.ldw = ldx; p.N = T;
+  p.nbatch = B; p.a_bs = 0; p.w_bs = (int64_t)T * ldx; p.o_bs = (int64_t)wv.N * Tpad;
+  p.out = vt; p.out_ld = Tpad; p.zeros = c.zeros;
+  launch_conv_gemm(c.st, p);
+}
+
+class ClipText : public TextEncoder {
+ public:
+  explicit ClipText(const cd_net_desc& d) {
+    desc = d;
+    width_ = d.model_channels; layers_n_ = d.num_res_blocks; heads_ = d.num_heads;
+    mlp_ = d.context_dim; vocab_ = d.in_channels; maxpos_ = d.image_size;
+    CD_CHECK(width_ > 0 && width_ % 64 == 0 && heads_ > 0 && width_ % heads_ == 0 && (width_ / heads_) % 8 == 0 &&
+                 width_ / heads_ <= 160,
+             "clip text: width %d / heads %d unsupported", width_, heads_);
+    CD_CHECK(layers_n_ > 0 && mlp_ % 64 == 0 && vocab_ > 0 && maxpos_ > 0, "clip text: bad descriptor");
+    const std::string root = "text_model.";
+    tok_ = params.new_vec(vocab_ * width_);
+    pos_ = params.new_vec(maxpos_ * width_);
+    params.mat_f32(root + "embeddings.token_embedding.weight", tok_, vocab_, width_);
+    params.mat_f32(root + "embeddings.position_embedding.weight", pos_, maxpos_, width_);
+    const int D = width_;
+    for (int i = 0; i < layers_n_; ++i) {
+      const std::string lp = root + "encoder.layers." + std::to_string(i);
+      ClipLayer L;
+      L.ln1 = mk_ln(params, lp + ".layer_norm1", D);
+      L.ln2 = mk_ln(params, lp + ".layer_norm2", D);
+      L.qk = params.new_conv(2 * D, D, 1, 1, true);
+      params.conv_rows(lp + ".self_attn.q_proj.weight", {D, D}, L.qk, 0, D, 0, D, 0);
+      params.conv_rows(lp + ".self_attn.k_proj.weight", {D, D}, L.qk, D, D, 0, D, 0);
+      params.bias_rows(lp + ".self_attn.q_proj.bias", D, L.qk->b, 0, D, 0, D, 0);
+      params.bias_rows(lp + ".self_attn.k_proj.bias", D, L.qk->b, D, D, 0, D, 0);
+      L.v = params.new_conv(D, D, 1, 1, false);
+      params.conv_weight(lp + ".self_attn.v_proj.weight", L.v, 2);
+      L.vbias = params.new_vec(D);  // added to the attention output: rows of softmax(.) sum to 1
+      params.vec(lp + ".self_attn.v_proj.bias", L.vbias, D);
+      L.o = mk_linear(params, lp + ".self_attn.out_proj", D, D);
+      L.fc1 = mk_linear(params, lp + ".mlp.fc1", mlp_, D);
+      L.fc2 = mk_linear(params, lp + ".mlp.fc2", D, mlp_);
+      layers_.push_back(L);
+    }
+    final_ = mk_ln(params, root + "final_layer_norm", D);
+  }
+  int kind() const override { return CD_NET_CLIP_TEXT; }
+  int width() const override { return width_; }
+  int max_positions() const override { return maxpos_; }
+
+  // ids [B][L] int32 (device) -> last_hidden_state fp32 [B][L][width]
+  void encode(Ctx& c, const int* ids, int B, int L, float* out) override {
+    CD_CHECK(L > 0 && L <= maxpos_, "clip text: sequence length %d exceeds %d positions", L, maxpos_);
+    const size_t mk = c.arena->mark();
+    const int D = width_, dh = D / heads_;
+    Act h = alloc_act(c, B, L, 1, D);
+    launch_embed_tokens(c.st, ids, tok_, pos_, h.p, B, L, D, vocab_);
+    const int Tpad = round_up(L, 64);
+    bf16_t* vt = (bf16_t*)c.arena->alloc((size_t)B * D * Tpad * 2);
+    HIP_CHECK(hipMemsetAsync(vt, 0, (size_t)B * D * Tpad * 2, c.st));
+    const float scale = 1.0f / sqrtf((float)dh);  // CLIPAttention: q * head_dim**-0.5
+    ConvOpts p0; p0.pad = 0;
+    for (const ClipLayer& Lw : layers_) {
+      const size_t m2 = c.arena->mark();
+      Act n1 = layernorm_fwd(c, Lw.ln1, h);
+      Act qk = conv_fwd(c, *Lw.qk, n1, nullptr, p0);  // [B*L][2D]
+      vt_gemm(c, *Lw.v, n1.p, n1.ld, B, L, Tpad, vt);
+      Act a = alloc_act(c, B, L, 1, D);
+      AttnParams ap;
+      ap.q = qk.p; ap.k = qk.p + D; ap.vt = vt; ap.o = a.p;
+      ap.B = B; ap.H = heads_; ap.Tq = L; ap.Tk = L; ap.D = dh;
+      ap.ldq = qk.ld; ap.ldk = qk.ld; ap.ldo = a.ld;
+      ap.q_bs = (int64_t)L * qk.ld; ap.k_bs = (int64_t)L * qk.ld; ap.o_bs = (int64_t)L * a.ld;
+      ap.vt_dpad = dh; ap.vt_tpad = Tpad; ap.scale = scale; ap.obias = Lw.vbias; ap.causal = 1;
+      launch_attention(c.st, ap);
+      ConvOpts o; o.pad = 0; o.resid = &h; o.out = h.p; o.out_ld = h.ld;  // h += out_proj(attn), in place
+      conv_fwd(c, *Lw.o, a, nullptr, o);
+      Act n2 = layernorm_fwd(c, Lw.ln2, h);
+      ConvOpts f1; f1.pad = 0; f1.act = ACT_QGELU;
+      Act g = conv_fwd(c, *Lw.fc1, n2, nullptr, f1);
+      ConvOpts f2; f2.pad = 0; f2.resid = &h; f2.out = h.p; f2.out_ld = h.ld;  // h += fc2(quick_gelu(fc1))
+      conv_fwd(c, *Lw.fc2, g, nullptr, f2);
+      c.arena->release(m2);
+    }
+    Act y = layernorm_fwd(c, final_, h);
+    launch_nhwc_to_nchw(c.st, y.p, 0, y.ld, out, B * L, D, 1, 1.f, 0.f);  // 16-bit rows -> fp32 [B][L][D]
+    c.arena->release(mk);
+  }
+
+ private:
+  int width_ = 0, layers_n_ = 0, heads_ = 0, mlp_ = 0, vocab_ = 0, maxpos_ = 0;
+  float *tok_ = nullptr, *pos_ = nullptr;
+  std::vector<ClipLayer> layers_;
+  LNW final_;
+};
+
+}  // namespace
+
+std::unique_ptr<TextEncoder> make_clip_text(const cd_net_desc& d) { return std::unique_ptr<TextEncoder>(new ClipText(d)); }
+
+}  // namespace cd

@@ -417,6 +417,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
       } else if (p.act == ACT_GELU) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      } else if (p.act == ACT_QGELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
       }
     }
     if (p.resid) {

@@ -132,6 +132,26 @@ __global__ __launch_bounds__(256) void k_vec_linear(const float* __restrict__ x,
   }
 }
 
+// CLIPTextEmbeddings.forward (transformers models/clip/modeling_clip.py): token_embedding(ids) + position_embedding
+__global__ void k_embed_tokens(const int* __restrict__ ids, const float* __restrict__ tok,
+                               const float* __restrict__ pos, bf16_t* __restrict__ out, int B, int L, int D, int vocab) {
+  const int nvec = D / 8;
+  const int64_t n = (int64_t)B * L * nvec;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int v = (int)(i % nvec);
+    const int64_t bl = i / nvec;
+    const int l = (int)(bl % L);
+    int id = ids[bl];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const float* tr = tok + (int64_t)id * D + v * 8;
+    const float* pr = pos + (int64_t)l * D + v * 8;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = tr[e] + pr[e];
+    *(uint4*)(out + bl * D + v * 8) = pack8(f);
+  }
+}
+
 __global__ void k_avgpool2(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int C) {
   const int Ho = H / 2, Wo = W / 2, nvec = C / 8;
   const int64_t n = (int64_t)B * Ho * Wo * nvec;
@@ -259,6 +279,12 @@ void launch_posterior_sample(hipStream_t st, const float* mom, int ld, const flo
   const int64_t n = (int64_t)B * zc * HW;
   hipLaunchKernelGGL(k_posterior_sample, dim3(ew_grid(n)), dim3(256), 0, st, mom, ld, noise, seed, z,
                      B, zc, HW, scale, use_mean);
+}
+void launch_embed_tokens(hipStream_t st, const int* ids, const float* tok, const float* pos, bf16_t* out, int B,
+                         int L, int D, int vocab) {
+  CD_CHECK(D % 8 == 0, "embed_tokens: width %% 8");
+  const int64_t n = (int64_t)B * L * (D / 8);
+  hipLaunchKernelGGL(k_embed_tokens, dim3(ew_grid(n)), dim3(256), 0, st, ids, tok, pos, out, B, L, D, vocab);
 }
 void launch_fill_f32(hipStream_t st, float* p, float v, int64_t n) {
   hipLaunchKernelGGL(k_fill_f32, dim3(ew_grid(n)), dim3(256), 0, st, p, v, n);

@@ -194,4 +194,12 @@ class VAE : public Net {
 };
 std::unique_ptr<VAE> make_vae_kl(const cd_net_desc& d);
 
+class TextEncoder : public Net {  // token ids -> conditioning sequence
+ public:
+  virtual void encode(Ctx& c, const int* ids_dev, int B, int L, float* out) = 0;  // fp32 [B][L][width]
+  virtual int width() const = 0;
+  virtual int max_positions() const = 0;
+};
+std::unique_ptr<TextEncoder> make_clip_text(const cd_net_desc& d);
+
 }  // namespace cd

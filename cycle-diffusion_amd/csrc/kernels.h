@@ -42,7 +42,7 @@ void launch_set_int(hipStream_t st, int* p, int v);
 void launch_add_int(hipStream_t st, int* p, int d);
 
 // ---------------------------------------------------------------- implicit-GEMM conv / GEMM (conv_gemm.hip)
-enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_GEGLU = 3 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_GEGLU = 3, ACT_QGELU = 4 };  // QGELU: x*sigmoid(1.702x) (CLIP)
 
 struct ConvGemmParams {
   // A operand: activations, NHWC bf16; optional second source = channel concat (th.cat, openaimodel.py:736)
@@ -172,6 +172,7 @@ struct AttnParams {
   int vt_dpad = 0, vt_tpad = 0;
   float scale = 1.0f;
   const float* obias = nullptr;  // [H*D] added to the output (value-projection bias: rows of P sum to 1)
+  int causal = 0;                // 1: key j is visible to query i only if j <= i (CLIP text transformer)
 };
 void launch_attention(hipStream_t st, const AttnParams& p);
 // V [B][Tk][ldv] (head h at column h*D) -> Vt [B][H][Dpad][Tpad], zero padded
@@ -202,6 +203,9 @@ void launch_posterior_sample(hipStream_t st, const float* mom, int ld, const flo
                              uint64_t seed, float* z, int B, int zc, int HW, float scale,
                              int use_mean);
 void launch_fill_f32(hipStream_t st, float* p, float v, int64_t n);
+// token + position embedding lookup: out[b][l][:] = tok[ids[b][l]][:] + pos[l][:] (fp32 tables -> 16-bit rows)
+void launch_embed_tokens(hipStream_t st, const int* ids, const float* tok, const float* pos, bf16_t* out, int B,
+                         int L, int D, int vocab);
 void launch_copy_strided_bf16(hipStream_t st, const bf16_t* src, int lds, bf16_t* dst, int ldd,
                               int64_t rows, int cols);
 

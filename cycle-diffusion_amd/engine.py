@@ -56,6 +56,13 @@ def kl_f8_vae_desc():
                      num_res_blocks=2, channel_mult=(1, 2, 4, 4), z_channels=4, embed_dim=4, double_z=True)
 
 
+def clip_text_desc(width=768, layers=12, heads=12, mlp=3072, vocab=49408, positions=77):
+    """HF CLIPTextConfig of "openai/clip-vit-large-patch14" (ldm/modules/encoders/modules.py:138-141)"""
+    return make_desc(_ffi.CD_NET_CLIP_TEXT, image_size=positions, in_channels=vocab, out_channels=width,
+                     model_channels=width, num_res_blocks=layers, channel_mult=(1,), num_heads=heads,
+                     context_dim=mlp)
+
+
 def afhq_iddpm_desc(image_size=256):
     """improved_ddpm/script_util.py:5-22,45-104 (AFHQ_DICT; learn_sigma -> 6 output channels)"""
     return make_desc(_ffi.CD_NET_UNET_OPENAI, image_size=image_size, in_channels=3, out_channels=6,
@@ -150,7 +157,8 @@ class Engine:
             if len(shape) == 1:
                 base = name.rsplit(".", 1)[0]
                 is_norm = name.endswith("weight") and (".norm" in name or "in_layers.0" in name or "out_layers.0" in name
-                                                       or name.startswith("out.0") or "norm_out" in name)
+                                                       or name.startswith("out.0") or "norm_out" in name
+                                                       or "layer_norm" in name)
                 if is_norm:
                     t = 1.0 + 0.05 * torch.randn(shape, generator=g)
                 else:
@@ -179,6 +187,14 @@ class Engine:
 
     def _out_channels(self, net):
         return self._descs[net].out_channels
+
+    def text_encode(self, net, tokens):
+        """tokens [B, L] integer ids -> last_hidden_state [B, L, width] fp32 (FrozenCLIPEmbedder.forward)."""
+        ids = tokens.to(device=self.device, dtype=torch.int32).contiguous()
+        B, L = ids.shape
+        out = torch.empty((B, L, self._descs[net].model_channels), device=self.device, dtype=torch.float32)
+        check(self.lib.cd_text_encode(self.h, net, ptr(ids), B, L, ptr(out)))
+        return out
 
     def vae_encode(self, net, img, noise=None, seed=0, sample=True, scale=0.18215):
         img = self._f32(img)

@@ -46,7 +46,7 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
 
     def __init__(self, source_model_type, custom_steps, eta, white_box_steps, skip_steps,
                  encoder_unconditional_guidance_scales=None, decoder_unconditional_guidance_scales=None,
-                 n_trials=None, cond_stage=None, ranker=None, device=None):
+                 n_trials=None, cond_stage=None, ranker=None, device=None, text_encoder=None):
         super().__init__()
         self.encoder_unconditional_guidance_scales = encoder_unconditional_guidance_scales
         self.decoder_unconditional_guidance_scales = decoder_unconditional_guidance_scales
@@ -62,6 +62,11 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
         ckpt = self.checkpoint_path(source_model_type)
         self.weights_origin = load_or_init_weights(self.engine, ckpt, {
             self.unet: "model.diffusion_model.", self.vae: "first_stage_model."})
+        if cond_stage is None and text_encoder == "clip":
+            # `[gan] text_encoder = clip`: FrozenCLIPEmbedder on the engine (768-wide contexts: the SD U-Net)
+            from .text_encoders import FrozenCLIPEmbedderHIP
+            assert udesc.context_dim == 768, "the CLIP ViT-L/14 text encoder conditions the SD-v1 U-Net"
+            cond_stage = FrozenCLIPEmbedderHIP(self.engine)
         self.cond_stage = cond_stage or StandInTextEmbedder(udesc.context_dim)
         self.ranker = ranker
         self.alphas_cumprod = schedule.latent_alphas_cumprod(1000, self.LINEAR_START, self.LINEAR_END)

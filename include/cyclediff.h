@@ -27,14 +27,18 @@ extern "C" {
 
 typedef struct cd_engine* cd_handle;
 
-enum { CD_NET_UNET_OPENAI = 1, CD_NET_UNET_HO = 2, CD_NET_VAE_KL = 3 };
+enum { CD_NET_UNET_OPENAI = 1, CD_NET_UNET_HO = 2, CD_NET_VAE_KL = 3, CD_NET_CLIP_TEXT = 4 };
 enum { CD_SCHED_DDIM = 0, CD_SCHED_DDPM = 1 };
 
 /* Architecture descriptor (the hyper-parameters of the reference's YAML / dict configs):
  *   UNET_OPENAI : ldm/modules/diffusionmodules/openaimodel.py:413-470 (SD v1, LDM text2img) and
  *                 model/lib/ddpm_ddim/models/improved_ddpm/unet.py:401-470 (i_DDPM AFHQ)
  *   UNET_HO     : model/lib/ddpm_ddim/models/ddpm/diffusion.py:192-290
- *   VAE_KL      : ldm/models/autoencoder.py:285-333 + diffusionmodules/model.py:368-568 */
+ *   VAE_KL      : ldm/models/autoencoder.py:285-333 + diffusionmodules/model.py:368-568
+ *   CLIP_TEXT   : the HF `CLIPTextModel` behind FrozenCLIPEmbedder (ldm/modules/encoders/modules.py:136-161);
+ *                 descriptor fields reused: model_channels = width (768), num_res_blocks = layers (12),
+ *                 num_heads (12), context_dim = MLP width (3072), in_channels = vocabulary (49408),
+ *                 image_size = positions (77); weights keyed by `text_model.*` (HF state_dict names) */
 typedef struct cd_net_desc {
   int kind;
   int image_size;          /* spatial size of the network input (latent 64, pixel 256, ...)      */
@@ -89,6 +93,11 @@ int cd_net_missing_params(cd_handle h, int net, int* n_missing, char* first_name
  * eps_out [B,Cout,H,W]. */
 int cd_unet_forward(cd_handle h, int net, const float* x, const float* t, const float* ctx, int B,
                     int ctx_len, float* eps_out);
+
+/* c = FrozenCLIPEmbedder(text): last_hidden_state of the CLIP text transformer for already tokenised text
+ * (modules.py:148-158: tokenizer(..., max_length=77, padding="max_length") then transformer(input_ids)).
+ * tokens [B,L] int32 (device), out [B,L,width] fp32 - the `ctx` tensors of the sampler entry points. */
+int cd_text_encode(cd_handle h, int net, const int32_t* tokens, int B, int L, float* out);
 
 /* z0 = scale * posterior(E(img)).sample() (or .mode() when sample==0) — encode_first_stage +
  * get_first_stage_encoding (ddpm.py:817-854, 536-543); img [B,3,R,R] in [-1,1]; noise [B,zc,R/8,R/8]
