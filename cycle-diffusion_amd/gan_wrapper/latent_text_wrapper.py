@@ -6,9 +6,13 @@ encode(image, encode_text) -> z_ensemble and forward(z_ensemble, original_img, e
 decode_text) -> img contracts, same ensemble ordering (trial -> encoder scale -> skip_steps, then
 decoder scales) and z layout torch.stack(z_list, dim=1).view(bsz, -1).
 
-Out of scope here: the CLIP / BERT text encoders and the DirectionalCLIP ranker.
-Conditioning enters through `cond_stage` (a callable list[str] -> [B, 77, context_dim]); when no
-real encoder is plugged in, a deterministic stand-in embedding is used and SAYS SO in its name.
+Conditioning enters through `cond_stage` (a callable list[str] -> [B, 77, context_dim]):
+`[gan] text_encoder = clip` runs the CLIP text transformer on the engine (text_encoders.py); otherwise a
+deterministic stand-in embedding is used and SAYS SO in its name. The DirectionalCLIP ranker and the LDM BERT
+encoder stay out of scope.
+
+Ensemble members that share (guidance scale, skip) differ only in their noise: they are folded into the batch
+dimension of ONE engine call - same draws, same member order, larger GEMMs.
 """
 import hashlib
 import os
@@ -43,10 +47,13 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
     SAMPLE_POSTERIOR = True
     LINEAR_START, LINEAR_END = 0.00085, 0.0120
     SCALE_FACTOR = 0.18215
+    VAE_DESC = staticmethod(kl_f8_vae_desc)
+    MAX_FOLD = 32  # samples per engine call when ensemble members are folded into the batch
 
     def __init__(self, source_model_type, custom_steps, eta, white_box_steps, skip_steps,
                  encoder_unconditional_guidance_scales=None, decoder_unconditional_guidance_scales=None,
-                 n_trials=None, cond_stage=None, ranker=None, device=None, text_encoder=None):
+                 n_trials=None, cond_stage=None, ranker=None, device=None, text_encoder=None,
+                 noise_on_cpu=False, fold_ensemble=True):
         super().__init__()
         self.encoder_unconditional_guidance_scales = encoder_unconditional_guidance_scales
         self.decoder_unconditional_guidance_scales = decoder_unconditional_guidance_scales
@@ -54,11 +61,16 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
         self.eta, self.custom_steps = eta, custom_steps
         self.white_box_steps, self.skip_steps = white_box_steps, skip_steps
         self.resolution = self.RESOLUTION
+        # parity runs draw every noise tensor on the CPU in the reference's order; throughput
+        # runs draw on the device
+        self.noise_on_cpu, self.fold_ensemble = bool(noise_on_cpu), bool(fold_ensemble)
         self.engine = get_engine(device)
         udesc = self.UNET_DESC()
         self.channels, self.image_size = udesc.in_channels, udesc.image_size
         self.unet = self.engine.create_net(udesc)
-        self.vae = self.engine.create_net(kl_f8_vae_desc())
+        vdesc = self.VAE_DESC()
+        self.vae = self.engine.create_net(vdesc)
+        self.vae_factor = 2 ** (vdesc.n_mult - 1)
         ckpt = self.checkpoint_path(source_model_type)
         self.weights_origin = load_or_init_weights(self.engine, ckpt, {
             self.unet: "model.diffusion_model.", self.vae: "first_stage_model."})
@@ -83,6 +95,23 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
     def _schedule(self):
         return schedule.DDIMSchedule(self.alphas_cumprod, self.custom_steps, self.eta)
 
+    def _randn(self, shape):
+        if self.noise_on_cpu:
+            return torch.randn(shape).to(self.device)
+        return torch.randn(shape, device=self.device)
+
+    def _groups(self, keys):
+        """indices of ensemble members grouped by key, in first-appearance order; singletons when folding is off"""
+        if not self.fold_ensemble:
+            return [[i] for i in range(len(keys))]
+        order, groups = [], {}
+        for i, k in enumerate(keys):
+            if k not in groups:
+                groups[k] = []
+                order.append(k)
+            groups[k].append(i)
+        return [groups[k] for k in order]
+
     # ---- encode (sd_wrapper:169-206)
     def encode(self, image, encode_text):
         image = (image - 0.5) * 2.0
@@ -92,42 +121,68 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
         noise = None
         if self.SAMPLE_POSTERIOR:
             # DiagonalGaussianDistribution.sample draws on the CPU and moves (distributions.py:36)
-            h = self.resolution // 8
+            h = self.resolution // self.vae_factor
             noise = torch.randn((bsz, self.channels, h, h)).to(self.device)
         x0 = self.engine.vae_encode(self.vae, image, noise=noise, sample=self.SAMPLE_POSTERIOR,
                                     scale=self.SCALE_FACTOR)
         sch = self._schedule()
-        z_ensemble = []
+        assert self.eta > 0
+        c, uc = self.get_condition(encode_text, bsz)
+        # members in the reference's order: trial -> encoder scale -> skip; noise drawn member by member in the
+        # draw order of _ddpm_ddim_encoding: randn_like(x0) then K-1 x randn(shape) (ddim.py:479,599)
+        members = []
         for _trial in range(self.n_trials):
             for enc_scale in self.encoder_unconditional_guidance_scales:
                 for skip in self.skip_steps:
-                    c, uc = self.get_condition(encode_text, bsz)
-                    assert self.eta > 0
                     K = len(sch) - skip
                     n_loop = min(K, self.white_box_steps - skip - 1) if self.white_box_steps != -1 else 0
                     assert n_loop == K, "white_box_steps shorter than the chain is not used by the reference configs"
-                    # draw order of _ddpm_ddim_encoding: randn_like(x0) then K-1 x randn(shape) (ddim.py:479,599)
-                    nz = torch.randn((K,) + tuple(x0.shape), device=self.device)
-                    z = self.engine.dpm_encode(self.unet, _ffi.CD_SCHED_DDIM, x0, sch.coef_encode(skip), ctx_c=c,
-                                               ctx_uc=uc, guidance=float(enc_scale), noise=nz, last_uses_x0=True)
-                    z_ensemble.append(z.view(bsz, -1))
+                    if self.noise_on_cpu:
+                        nz = torch.stack([self._randn(tuple(x0.shape)) for _ in range(K)], 0)
+                    else:
+                        nz = self._randn((K,) + tuple(x0.shape))
+                    members.append((float(enc_scale), int(skip), nz))
+        z_ensemble = [None] * len(members)
+        per_call = max(1, self.MAX_FOLD // bsz)
+        for grp in self._groups([(m[0], m[1]) for m in members]):
+            enc_scale, skip = members[grp[0]][0], members[grp[0]][1]
+            for j0 in range(0, len(grp), per_call):
+                idx = grp[j0:j0 + per_call]
+                n = len(idx)
+                z = self.engine.dpm_encode(self.unet, _ffi.CD_SCHED_DDIM, x0.repeat(n, 1, 1, 1), sch.coef_encode(skip),
+                                           ctx_c=c.repeat(n, 1, 1), ctx_uc=uc.repeat(n, 1, 1), guidance=enc_scale,
+                                           noise=torch.cat([members[i][2] for i in idx], dim=1), last_uses_x0=True)
+                for j, i in enumerate(idx):
+                    z_ensemble[i] = z[j * bsz:(j + 1) * bsz].reshape(bsz, -1)
         return z_ensemble
 
     # ---- generate (sd_wrapper:142-167)
     def generate(self, z_ensemble, decode_text):
-        img_ensemble = []
         sch = self._schedule()
+        n_dec = len(self.decoder_unconditional_guidance_scales)
+        bsz = z_ensemble[0].shape[0]
+        c, uc = self.get_condition(decode_text, bsz)
+        jobs = []  # (output slot, skip, decoder scale, z) in the reference's order: z member -> decoder scale
         for i, z in enumerate(z_ensemble):
             skip = self.skip_steps[i % len(self.skip_steps)]
-            bsz = z.shape[0]
             zz = z.view(bsz, self.white_box_steps - skip, self.channels, self.image_size, self.image_size)
-            for dec_scale in self.decoder_unconditional_guidance_scales:
-                c, uc = self.get_condition(decode_text, bsz)
-                x = self.engine.ddim_decode(self.unet, _ffi.CD_SCHED_DDIM, zz.contiguous(), sch.coef_decode(skip),
-                                            ctx_c=c, ctx_uc=uc, guidance=float(dec_scale))
+            for j, dec_scale in enumerate(self.decoder_unconditional_guidance_scales):
+                jobs.append((i * n_dec + j, int(skip), float(dec_scale), zz))
+        img_ensemble = [None] * len(jobs)
+        per_call = max(1, self.MAX_FOLD // bsz)
+        for grp in self._groups([(jb[1], jb[2]) for jb in jobs]):
+            skip, dec_scale = jobs[grp[0]][1], jobs[grp[0]][2]
+            for j0 in range(0, len(grp), per_call):
+                idx = grp[j0:j0 + per_call]
+                n = len(idx)
+                x = self.engine.ddim_decode(self.unet, _ffi.CD_SCHED_DDIM,
+                                            torch.cat([jobs[i][3] for i in idx], dim=0).contiguous(),
+                                            sch.coef_decode(skip), ctx_c=c.repeat(n, 1, 1), ctx_uc=uc.repeat(n, 1, 1),
+                                            guidance=dec_scale)
                 # decode_first_stage, then post_process (x+1)/2 fused into the final layout kernel
-                img_ensemble.append(self.engine.vae_decode(self.vae, x, scale=self.SCALE_FACTOR, out_mul=0.5,
-                                                           out_add=0.5))
+                img = self.engine.vae_decode(self.vae, x, scale=self.SCALE_FACTOR, out_mul=0.5, out_add=0.5)
+                for j, i in enumerate(idx):
+                    img_ensemble[jobs[i][0]] = img[j * bsz:(j + 1) * bsz]
         return img_ensemble
 
     def forward(self, z_ensemble, original_img, encode_text, decode_text):

@@ -1,0 +1,140 @@
+"""The gan_wrapper drop-ins through their reference API (encode(image, text) -> z_ensemble; __call__(z_ensemble,
+original, src_text, tgt_text) -> image; stable_diffusion_stochastic_text_wrapper.py:169-249) on a small SD-shaped
+network, against the CPU oracle composed the way the reference composes it: VAE encode -> posterior sample ->
+DPM-Encoder per (trial, encoder scale, skip) -> decode per decoder scale -> VAE decode -> (x+1)/2.
+Noise is drawn on the CPU in the reference's draw order (noise_on_cpu=True) so both sides see the same numbers.
+Also pins the ensemble contract: member order, z layout, and that folding members into the batch changes nothing
+beyond 16-bit rounding."""
+import pytest
+import torch
+
+import golden_util as gu
+from cycle_diffusion_amd import _ffi
+from cycle_diffusion_amd.gan_wrapper.latent_text_wrapper import _LatentStochasticTextWrapper
+from oracle import nets, samplers
+from test_gpu_models import tiny_sd_desc, tiny_vae_desc
+
+pytestmark = pytest.mark.gpu
+
+FMT = 1.0 if _ffi.load_library().cd_act_format() == 1 else 8.0
+STEPS, WB = 19, 20
+PSNR_FLOOR = 40.0 if FMT == 1.0 else 25.0  # dB, images in [0, 1]
+
+
+class TinyTextWrapper(_LatentStochasticTextWrapper):
+    UNET_DESC = staticmethod(tiny_sd_desc)
+    VAE_DESC = staticmethod(tiny_vae_desc)
+    RESOLUTION = 64  # tiny VAE: factor 4 -> latent 16
+    SAMPLE_POSTERIOR = True
+
+    @staticmethod
+    def checkpoint_path(source_model_type):
+        return None
+
+
+class FixedEmbedder:
+    def __init__(self):
+        self.table = {}
+
+    def __call__(self, texts):
+        out = []
+        for t in texts:
+            if t not in self.table:
+                g = torch.Generator().manual_seed(1000 + len(self.table))
+                self.table[t] = torch.randn(77, 64, generator=g)
+            out.append(self.table[t])
+        return torch.stack(out, 0)
+
+
+def _make(fold, **kw):
+    emb = FixedEmbedder()
+    args = dict(source_model_type="none", custom_steps=STEPS, eta=0.1, white_box_steps=WB, skip_steps=[0, 4],
+                encoder_unconditional_guidance_scales=[1.0], decoder_unconditional_guidance_scales=[1.0, 3.0],
+                n_trials=2, cond_stage=emb, ranker=lambda img, orig, s, t: img.flatten(1).mean(1),
+                noise_on_cpu=True, fold_ensemble=fold)
+    args.update(kw)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        w = TinyTextWrapper(**args)
+    usd = nets.synth_state_dict(w.engine.net_params(w.unet), 31)
+    vsd = nets.synth_state_dict(w.engine.net_params(w.vae), 32)
+    assert w.engine.load_state_dict(w.unet, usd)[0] == 0 and w.engine.load_state_dict(w.vae, vsd)[0] == 0
+    return w, emb, usd, vsd
+
+
+def _oracle(emb, usd, vsd, image, src, tgt, seed):
+    torch.manual_seed(seed)
+    B = image.shape[0]
+    with torch.no_grad():
+        mom = nets.vae_encode_moments(vsd, gu.TINY_VAE_CFG, (image - 0.5) * 2.0)
+        x0 = nets.posterior_sample(mom, torch.randn(B, 4, 16, 16)) * 0.18215
+        unet = lambda x, t, c: nets.openai_unet(usd, gu.TINY_SD_CFG, x, t, c)
+        c_src, c_tgt, uc = emb(src), emb(tgt), emb(B * [""])
+        zs, imgs = [], []
+        for _trial in range(2):
+            for skip in (0, 4):
+                K = STEPS - skip
+                nz = [torch.randn(x0.shape) for _ in range(K)]
+                zs.append((skip, samplers.latent_encode(samplers.cfg_model(unet, c_src, uc, 1.0), x0, STEPS, 0.1, nz,
+                                                        skip_steps=skip, white_box_steps=WB)))
+        for skip, z in zs:
+            for g in (1.0, 3.0):
+                x = samplers.latent_decode(samplers.cfg_model(unet, c_tgt, uc, g), z[0], torch.stack(z[1:], 1), STEPS,
+                                           0.1, skip_steps=skip)
+                imgs.append((nets.vae_decode(vsd, gu.TINY_VAE_CFG, x / 0.18215) + 1.0) / 2.0)
+    return zs, imgs
+
+
+def test_text_wrapper_api_vs_oracle(report):
+    image = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(2))
+    src, tgt = ["a photo of a cat", "a red car"], ["a photo of a dog", "a blue car"]
+    w, emb, usd, vsd = _make(fold=True)
+    torch.manual_seed(77)
+    with torch.no_grad():
+        z_ens = w.encode(image.cuda(), src)
+        imgs = w.generate(z_ens, tgt)
+    zs_ref, imgs_ref = _oracle(emb, usd, vsd, image, src, tgt, 77)
+    # contract: 2 trials x 1 encoder scale x 2 skips, ordered trial -> scale -> skip; z = stack(z_list, 1).view(B, -1)
+    assert len(z_ens) == 4 and len(imgs) == 8
+    worst_z, worst_img, min_psnr = 0.0, 0.0, 1e9
+    for i, (skip, zref) in enumerate(zs_ref):
+        assert z_ens[i].shape == (2, (WB - skip) * 4 * 16 * 16)
+        zr = torch.stack(zref, 1)
+        got = z_ens[i].view(2, WB - skip, 4, 16, 16).cpu()
+        assert torch.allclose(got[:, 0], zr[:, 0], atol=2e-3 * FMT)  # x_T: VAE rounding only
+        nr = zr.flatten(2).norm(dim=2)
+        worst_z = max(worst_z, ((got.flatten(2).norm(dim=2) - nr).abs() / nr).max().item())
+    for got, ref in zip(imgs, imgs_ref):
+        assert got.shape == (2, 3, 64, 64)
+        worst_img = max(worst_img, ((got.cpu() - ref).abs().max() / ref.abs().max()).item())
+        min_psnr = min(min_psnr, gu.psnr(got.cpu(), ref))
+    report.add("wrapper/text_api", z_norm_rel=worst_z, img_rel_to_max=worst_img, min_psnr_db=min_psnr)
+    # images in [0,1]: the stated tolerance is a PSNR floor against the reference path (north_star); the worst
+    # single pixel of the 8 candidates (CFG-3 decodes included) is reported and loosely bounded
+    assert worst_z < 2e-3 * FMT and min_psnr > PSNR_FLOOR and worst_img < 0.1 * FMT, (worst_z, min_psnr, worst_img)
+    # forward(): ranker scores -> per-sample argmax over the 8 candidates (sd_wrapper:219-235)
+    with torch.no_grad():
+        out = w(z_ens, image.cuda(), src, tgt)
+    scores = torch.stack([im.flatten(1).mean(1) for im in imgs], 1)
+    best = scores.argmax(1)
+    for b in range(2):
+        assert torch.equal(out[b], imgs[best[b].item()][b])
+
+
+def test_ensemble_folding_equals_member_by_member(report):
+    image = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(3))
+    src, tgt = ["x", "y"], ["z", "w"]
+    res = []
+    for fold in (True, False):
+        w, _, _, _ = _make(fold=fold)
+        torch.manual_seed(5)
+        with torch.no_grad():
+            z_ens = w.encode(image.cuda(), src)
+            res.append((z_ens, w.generate(z_ens, tgt)))
+    dz = max(((a - b).abs().max() / b.abs().max()).item() for a, b in zip(res[0][0], res[1][0]))
+    di = max(((a - b).abs().max() / b.abs().max()).item() for a, b in zip(res[0][1], res[1][1]))
+    ps = min(gu.psnr(a.cpu(), b.cpu()) for a, b in zip(res[0][1], res[1][1]))
+    report.add("wrapper/fold_vs_sequential", z_rel=dz, img_rel=di, min_psnr_db=ps)
+    # same noise, same member order; the folded batch may pick other tile / split-K choices (fp32 summation order)
+    assert dz < 2e-3 * FMT and ps > PSNR_FLOOR and di < 0.1 * FMT, (dz, ps, di)
