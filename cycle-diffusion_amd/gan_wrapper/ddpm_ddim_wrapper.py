@@ -41,8 +41,11 @@ def _desc(arch):
 class DDPMDDIMWrapper(torch.nn.Module):
 
     def __init__(self, source_model_type, sample_type, custom_steps, es_steps, source_model_path=None,
-                 refine_steps=0, refine_iterations=1, eta=None, t_0=None, enforce_class_input=None, device=None):
+                 refine_steps=0, refine_iterations=1, eta=None, t_0=None, enforce_class_input=None, device=None,
+                 noise_on_cpu=False):
         super().__init__()
+        # parity runs draw every noise tensor on the CPU, one tensor per reference draw, in the reference's order
+        self.noise_on_cpu = bool(noise_on_cpu)
         self.enforce_class_input = enforce_class_input
         self.custom_steps, self.es_steps = custom_steps, es_steps
         self.refine_steps, self.refine_iterations = refine_steps, refine_iterations
@@ -71,6 +74,11 @@ class DDPMDDIMWrapper(torch.nn.Module):
                                             refine_steps=refine_steps)
         self._anchor = torch.nn.Parameter(torch.zeros(1, device=self.engine.device), requires_grad=True)
 
+    def _randn(self, n, shape):
+        if self.noise_on_cpu:
+            return torch.stack([torch.randn(shape) for _ in range(n)], 0).to(self.device)
+        return torch.randn((n,) + tuple(shape), device=self.device)
+
     def encode(self, image, class_label=None):
         image = (image - 0.5) * 2.0
         assert image.shape[2] == image.shape[3] == self.resolution
@@ -80,7 +88,7 @@ class DDPMDDIMWrapper(torch.nn.Module):
         x0 = image.to(self.device, torch.float32)
         bsz = x0.shape[0]
         # draw order: sample_xt's randn_like, then one randn_like per posterior step (:313, :298/303)
-        nz = torch.randn((self.es_steps,) + tuple(x0.shape), device=self.device)
+        nz = self._randn(self.es_steps, tuple(x0.shape))
         z = self.engine.dpm_encode(self.net, self.sched.kind, x0, self.sched.coef_encode(), noise=nz,
                                    last_uses_x0=False)
         z = z.view(bsz, -1)
@@ -93,13 +101,13 @@ class DDPMDDIMWrapper(torch.nn.Module):
             raise NotImplementedError()
         bsz = z.shape[0]
         zz = z.view(bsz, self.es_steps, self.channels, self.resolution, self.resolution).contiguous()
-        last = torch.randn((1,) + tuple(zz[:, 0].shape), device=self.device)  # denoising_step's randn_like
+        last = self._randn(1, tuple(zz[:, 0].shape))  # denoising_step's randn_like
         x = self.engine.ddim_decode(self.net, self.sched.kind, zz, self.sched.coef_decode(),
                                     n_eps=self.es_steps - 1, noise_tail=last)
         if self.refine_steps:
             assert self.refine_steps < self.custom_steps
             for _ in range(self.refine_iterations):
-                nz = torch.randn((self.refine_steps + 1,) + tuple(x.shape), device=self.device)
+                nz = self._randn(self.refine_steps + 1, tuple(x.shape))
                 x = self.engine.pix_refine(self.net, self.sched.kind, x, self.sched.coef_refine(), noise=nz)
         return x
 

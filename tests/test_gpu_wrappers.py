@@ -138,3 +138,47 @@ def test_ensemble_folding_equals_member_by_member(report):
     report.add("wrapper/fold_vs_sequential", z_rel=dz, img_rel=di, min_psnr_db=ps)
     # same noise, same member order; the folded batch may pick other tile / split-K choices (fp32 summation order)
     assert dz < 2e-3 * FMT and ps > PSNR_FLOOR and di < 0.1 * FMT, (dz, ps, di)
+
+
+# ------------------------------------------------------------------ pixel wrapper (ddpm_ddim_wrapper.py:317-542)
+def _pixel_case(sample_type, eta, steps, seed):
+    from cycle_diffusion_amd.gan_wrapper.ddpm_ddim_wrapper import DDPMDDIMWrapper
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        w = DDPMDDIMWrapper(source_model_type="toy32", sample_type=sample_type, custom_steps=steps, es_steps=steps,
+                            eta=eta, noise_on_cpu=True)
+    sd = nets.synth_state_dict(w.engine.net_params(w.net), 41)
+    assert w.engine.load_state_dict(w.net, sd)[0] == 0
+    img = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(9))
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        z = w.encode(img.cuda())
+        out = w(z)
+    assert z.shape == (2, w.latent_dim) and out.shape == (2, 3, 32, 32)
+    # oracle, same draws in the same order: es_steps encode draws, then the decoder's one randn_like
+    torch.manual_seed(seed)
+    f = lambda x, t: nets.ho_unet(sd, gu.TOY_HO_CFG, x, t)
+    x0 = (img - 0.5) * 2.0
+    with torch.no_grad():
+        nz = [torch.randn(x0.shape) for _ in range(steps)]
+        zo = torch.stack(samplers.pixel_encode(f, x0, samplers.pixel_betas(), steps, steps, eta, nz, sample_type), 1)
+        xo = samplers.pixel_decode(f, zo, samplers.pixel_betas(), steps, steps, eta, torch.randn(x0.shape), sample_type)
+    ref = (xo + 1.0) / 2.0
+    zr = zo.flatten(2)
+    zg = z.view(2, steps, -1).cpu()
+    zerr = ((zg - zr).abs().amax(dim=2) / zr.abs().amax(dim=2)).max().item()
+    return zerr, gu.psnr(out.cpu(), ref), gu.psnr(out.cpu(), img)
+
+
+def test_pixel_wrapper_ddpm_type_vs_oracle(report):
+    zerr, p_ref, p_img = _pixel_case("ddpm", None, 20, 13)
+    report.add("wrapper/pixel_ddpm", z_rel=zerr, psnr_vs_oracle=p_ref, psnr_vs_input=p_img)
+    assert zerr < 6e-3 * FMT and p_ref > (60.0 if FMT == 1.0 else 30.0), (zerr, p_ref)
+
+
+def test_pixel_wrapper_ddim_type_vs_oracle(report):
+    # 'ddim' on a random-init net: eps slots are pinned, the image is held to the floor of test_c1
+    zerr, p_ref, p_img = _pixel_case("ddim", 0.1, 20, 14)
+    report.add("wrapper/pixel_ddim", z_rel=zerr, psnr_vs_oracle=p_ref, psnr_vs_input=p_img)
+    assert zerr < 2e-2 * FMT and p_ref > 9.0, (zerr, p_ref)
