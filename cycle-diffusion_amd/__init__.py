@@ -5,8 +5,9 @@ The directory name carries a hyphen (it is fixed by the project layout); import 
 `cycle_diffusion_amd` (the top-level shim package redirects here).
 """
 from . import _ffi  # noqa: F401
-from .engine import (Engine, afhq_iddpm_desc, clip_text_desc, ho_ddpm_desc, kl_f8_vae_desc,  # noqa: F401
+from .engine import (Engine, afhq_iddpm_desc, bert_xtransformer_desc, clip_text_desc, ho_ddpm_desc,  # noqa: F401
+                     kl_f8_vae_desc,
                      ldm_text_unet_desc, make_desc, sd_v1_unet_desc)
 
 __all__ = ["Engine", "make_desc", "sd_v1_unet_desc", "ldm_text_unet_desc", "kl_f8_vae_desc",
-           "afhq_iddpm_desc", "ho_ddpm_desc", "clip_text_desc"]
+           "afhq_iddpm_desc", "ho_ddpm_desc", "clip_text_desc", "bert_xtransformer_desc"]

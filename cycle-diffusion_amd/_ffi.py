@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcyclediff.so")
 
-CD_NET_UNET_OPENAI, CD_NET_UNET_HO, CD_NET_VAE_KL, CD_NET_CLIP_TEXT = 1, 2, 3, 4
+CD_NET_UNET_OPENAI, CD_NET_UNET_HO, CD_NET_VAE_KL, CD_NET_CLIP_TEXT, CD_NET_BERT_XTR = 1, 2, 3, 4, 5
 CD_SCHED_DDIM, CD_SCHED_DDPM = 0, 1
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
 

@@ -159,7 +159,8 @@ int cd_net_create(cd_handle h, const cd_net_desc* d, int* net_id) {
     case CD_NET_UNET_OPENAI: n = make_unet_openai(*d); break;
     case CD_NET_UNET_HO: n = make_unet_ho(*d); break;
     case CD_NET_VAE_KL: n = make_vae_kl(*d); break;
-    case CD_NET_CLIP_TEXT: n = make_clip_text(*d); break;
+    case CD_NET_CLIP_TEXT:
+    case CD_NET_BERT_XTR: n = make_clip_text(*d); break;
     default: CD_CHECK(false, "unknown net kind %d", d->kind);
   }
   h->nets.push_back(std::move(n));
@@ -322,7 +323,8 @@ int cd_unet_forward(cd_handle h, int net, const float* x, const float* t, const 
 int cd_text_encode(cd_handle h, int net, const int32_t* tokens, int B, int L, float* out) {
   CD_API_BEGIN
   enter_engine(h);
-  CD_CHECK(h && net >= 0 && net < (int)h->nets.size() && h->nets[net]->kind() == CD_NET_CLIP_TEXT,
+  CD_CHECK(h && net >= 0 && net < (int)h->nets.size() &&
+               (h->nets[net]->kind() == CD_NET_CLIP_TEXT || h->nets[net]->kind() == CD_NET_BERT_XTR),
            "net %d is not a text encoder", net);
   CD_CHECK(tokens && out && B > 0 && L > 0, "bad argument");
   Ctx c = h->ctx();

@@ -1,4 +1,6 @@
-// CLIP text transformer: the conditioning encoder of Stable Diffusion.
+// Text conditioning encoders: pre-LN token transformers on the engine's kernels.
+//
+// Variant CLIP (Stable Diffusion):
 //
 // Reference call site: FrozenCLIPEmbedder.forward (ldm/modules/encoders/modules.py:136-161) returns
 // `CLIPTextModel(...).last_hidden_state` of HF transformers (pinned 4.19.2 by the reference's environment;
@@ -7,6 +9,13 @@
 // transformers/models/clip/modeling_clip.py (CLIPTextEmbeddings, CLIPAttention, CLIPMLP, CLIPEncoderLayer,
 // CLIPTextTransformer); weights are keyed by that module's state_dict names (the names found under
 // `cond_stage_model.transformer.` in an SD checkpoint).
+//
+// Variant BERT_XTR (LDM text2img-large): BERTEmbedder.transformer = TransformerWrapper(num_tokens 30522, 77
+// positions, Encoder(dim 1280, depth 32)) of the vendored x-transformers copy
+// (model/lib/latentdiff/ldm/modules/encoders/modules.py:75-98; ldm/modules/x_transformer.py: Attention :215-330
+// - 8 heads x 64 whatever the width, bias-free q/k/v, no mask; FeedForward :194-211 - Linear, exact GELU, Linear;
+// AttentionLayers pre-norm residual blocks :371-560; TransformerWrapper.forward :600-640 with return_embeddings);
+// weights keyed by that module's state_dict names (`token_emb`, `pos_emb.emb`, `attn_layers.layers.{j}.{0,1}`, `norm`).
 //
 // Every contraction runs on the implicit-GEMM kernel (conv_gemm.hip), attention on the flash kernel with its
 // causal mask (attn.hip); residual adds, biases and quick-GELU live in GEMM epilogues.
@@ -52,40 +61,67 @@ class ClipText : public TextEncoder {
  public:
   explicit ClipText(const cd_net_desc& d) {
     desc = d;
+    xtr_ = d.kind == CD_NET_BERT_XTR;
     width_ = d.model_channels; layers_n_ = d.num_res_blocks; heads_ = d.num_heads;
     mlp_ = d.context_dim; vocab_ = d.in_channels; maxpos_ = d.image_size;
-    CD_CHECK(width_ > 0 && width_ % 64 == 0 && heads_ > 0 && width_ % heads_ == 0 && (width_ / heads_) % 8 == 0 &&
-                 width_ / heads_ <= 160,
-             "clip text: width %d / heads %d unsupported", width_, heads_);
-    CD_CHECK(layers_n_ > 0 && mlp_ % 64 == 0 && vocab_ > 0 && maxpos_ > 0, "clip text: bad descriptor");
-    const std::string root = "text_model.";
+    // x-transformers fixes heads x dim_head independently of the width (8 x 64 = 512 for a 1280-wide model)
+    inner_ = xtr_ ? heads_ * d.num_head_channels : width_;
+    causal_ = xtr_ ? 0 : 1;
+    act_ = xtr_ ? ACT_GELU : ACT_QGELU;
+    CD_CHECK(width_ > 0 && width_ % 64 == 0 && heads_ > 0 && inner_ % heads_ == 0 && inner_ % 64 == 0 &&
+                 (inner_ / heads_) % 8 == 0 && inner_ / heads_ <= 160,
+             "text encoder: width %d / heads %d / inner %d unsupported", width_, heads_, inner_);
+    CD_CHECK(layers_n_ > 0 && mlp_ % 64 == 0 && vocab_ > 0 && maxpos_ > 0, "text encoder: bad descriptor");
+    const int D = width_, I = inner_;
     tok_ = params.new_vec(vocab_ * width_);
     pos_ = params.new_vec(maxpos_ * width_);
-    params.mat_f32(root + "embeddings.token_embedding.weight", tok_, vocab_, width_);
-    params.mat_f32(root + "embeddings.position_embedding.weight", pos_, maxpos_, width_);
-    const int D = width_;
-    for (int i = 0; i < layers_n_; ++i) {
-      const std::string lp = root + "encoder.layers." + std::to_string(i);
-      ClipLayer L;
-      L.ln1 = mk_ln(params, lp + ".layer_norm1", D);
-      L.ln2 = mk_ln(params, lp + ".layer_norm2", D);
-      L.qk = params.new_conv(2 * D, D, 1, 1, true);
-      params.conv_rows(lp + ".self_attn.q_proj.weight", {D, D}, L.qk, 0, D, 0, D, 0);
-      params.conv_rows(lp + ".self_attn.k_proj.weight", {D, D}, L.qk, D, D, 0, D, 0);
-      params.bias_rows(lp + ".self_attn.q_proj.bias", D, L.qk->b, 0, D, 0, D, 0);
-      params.bias_rows(lp + ".self_attn.k_proj.bias", D, L.qk->b, D, D, 0, D, 0);
-      L.v = params.new_conv(D, D, 1, 1, false);
-      params.conv_weight(lp + ".self_attn.v_proj.weight", L.v, 2);
-      L.vbias = params.new_vec(D);  // added to the attention output: rows of softmax(.) sum to 1
-      params.vec(lp + ".self_attn.v_proj.bias", L.vbias, D);
-      L.o = mk_linear(params, lp + ".self_attn.out_proj", D, D);
-      L.fc1 = mk_linear(params, lp + ".mlp.fc1", mlp_, D);
-      L.fc2 = mk_linear(params, lp + ".mlp.fc2", D, mlp_);
-      layers_.push_back(L);
+    if (!xtr_) {
+      const std::string root = "text_model.";
+      params.mat_f32(root + "embeddings.token_embedding.weight", tok_, vocab_, D);
+      params.mat_f32(root + "embeddings.position_embedding.weight", pos_, maxpos_, D);
+      for (int i = 0; i < layers_n_; ++i) {
+        const std::string lp = root + "encoder.layers." + std::to_string(i);
+        ClipLayer L;
+        L.ln1 = mk_ln(params, lp + ".layer_norm1", D);
+        L.ln2 = mk_ln(params, lp + ".layer_norm2", D);
+        L.qk = params.new_conv(2 * D, D, 1, 1, true);
+        params.conv_rows(lp + ".self_attn.q_proj.weight", {D, D}, L.qk, 0, D, 0, D, 0);
+        params.conv_rows(lp + ".self_attn.k_proj.weight", {D, D}, L.qk, D, D, 0, D, 0);
+        params.bias_rows(lp + ".self_attn.q_proj.bias", D, L.qk->b, 0, D, 0, D, 0);
+        params.bias_rows(lp + ".self_attn.k_proj.bias", D, L.qk->b, D, D, 0, D, 0);
+        L.v = params.new_conv(D, D, 1, 1, false);
+        params.conv_weight(lp + ".self_attn.v_proj.weight", L.v, 2);
+        L.vbias = params.new_vec(D);  // added to the attention output: rows of softmax(.) sum to 1
+        params.vec(lp + ".self_attn.v_proj.bias", L.vbias, D);
+        L.o = mk_linear(params, lp + ".self_attn.out_proj", D, D);
+        L.fc1 = mk_linear(params, lp + ".mlp.fc1", mlp_, D);
+        L.fc2 = mk_linear(params, lp + ".mlp.fc2", D, mlp_);
+        layers_.push_back(L);
+      }
+      final_ = mk_ln(params, root + "final_layer_norm", D);
+    } else {
+      params.mat_f32("token_emb.weight", tok_, vocab_, D);
+      params.mat_f32("pos_emb.emb.weight", pos_, maxpos_, D);
+      for (int i = 0; i < layers_n_; ++i) {
+        const std::string la = "attn_layers.layers." + std::to_string(2 * i);      // (LayerNorm, Attention, Residual)
+        const std::string lf = "attn_layers.layers." + std::to_string(2 * i + 1);  // (LayerNorm, FeedForward, Residual)
+        ClipLayer L;
+        L.ln1 = mk_ln(params, la + ".0", D);
+        L.ln2 = mk_ln(params, lf + ".0", D);
+        L.qk = params.new_conv(2 * I, D, 1, 1, false);
+        params.conv_rows(la + ".1.to_q.weight", {I, D}, L.qk, 0, I, 0, I, 0);
+        params.conv_rows(la + ".1.to_k.weight", {I, D}, L.qk, I, I, 0, I, 0);
+        L.v = params.new_conv(I, D, 1, 1, false);
+        params.conv_weight(la + ".1.to_v.weight", L.v, 2);
+        L.o = mk_linear(params, la + ".1.to_out", D, I);
+        L.fc1 = mk_linear(params, lf + ".1.net.0.0", mlp_, D);
+        L.fc2 = mk_linear(params, lf + ".1.net.2", D, mlp_);
+        layers_.push_back(L);
+      }
+      final_ = mk_ln(params, "norm", D);
     }
-    final_ = mk_ln(params, root + "final_layer_norm", D);
   }
-  int kind() const override { return CD_NET_CLIP_TEXT; }
+  int kind() const override { return xtr_ ? CD_NET_BERT_XTR : CD_NET_CLIP_TEXT; }
   int width() const override { return width_; }
   int max_positions() const override { return maxpos_; }
 
@@ -93,31 +129,31 @@ class ClipText : public TextEncoder {
   void encode(Ctx& c, const int* ids, int B, int L, float* out) override {
     CD_CHECK(L > 0 && L <= maxpos_, "clip text: sequence length %d exceeds %d positions", L, maxpos_);
     const size_t mk = c.arena->mark();
-    const int D = width_, dh = D / heads_;
+    const int D = width_, I = inner_, dh = I / heads_;
     Act h = alloc_act(c, B, L, 1, D);
     launch_embed_tokens(c.st, ids, tok_, pos_, h.p, B, L, D, vocab_);
     const int Tpad = round_up(L, 64);
-    bf16_t* vt = (bf16_t*)c.arena->alloc((size_t)B * D * Tpad * 2);
-    HIP_CHECK(hipMemsetAsync(vt, 0, (size_t)B * D * Tpad * 2, c.st));
-    const float scale = 1.0f / sqrtf((float)dh);  // CLIPAttention: q * head_dim**-0.5
+    bf16_t* vt = (bf16_t*)c.arena->alloc((size_t)B * I * Tpad * 2);
+    HIP_CHECK(hipMemsetAsync(vt, 0, (size_t)B * I * Tpad * 2, c.st));
+    const float scale = 1.0f / sqrtf((float)dh);  // CLIPAttention: q * head_dim**-0.5; x-transformers: dim_head**-0.5
     ConvOpts p0; p0.pad = 0;
     for (const ClipLayer& Lw : layers_) {
       const size_t m2 = c.arena->mark();
       Act n1 = layernorm_fwd(c, Lw.ln1, h);
-      Act qk = conv_fwd(c, *Lw.qk, n1, nullptr, p0);  // [B*L][2D]
+      Act qk = conv_fwd(c, *Lw.qk, n1, nullptr, p0);  // [B*L][2*inner]
       vt_gemm(c, *Lw.v, n1.p, n1.ld, B, L, Tpad, vt);
-      Act a = alloc_act(c, B, L, 1, D);
+      Act a = alloc_act(c, B, L, 1, I);
       AttnParams ap;
-      ap.q = qk.p; ap.k = qk.p + D; ap.vt = vt; ap.o = a.p;
+      ap.q = qk.p; ap.k = qk.p + I; ap.vt = vt; ap.o = a.p;
       ap.B = B; ap.H = heads_; ap.Tq = L; ap.Tk = L; ap.D = dh;
       ap.ldq = qk.ld; ap.ldk = qk.ld; ap.ldo = a.ld;
       ap.q_bs = (int64_t)L * qk.ld; ap.k_bs = (int64_t)L * qk.ld; ap.o_bs = (int64_t)L * a.ld;
-      ap.vt_dpad = dh; ap.vt_tpad = Tpad; ap.scale = scale; ap.obias = Lw.vbias; ap.causal = 1;
+      ap.vt_dpad = dh; ap.vt_tpad = Tpad; ap.scale = scale; ap.obias = Lw.vbias; ap.causal = causal_;
       launch_attention(c.st, ap);
       ConvOpts o; o.pad = 0; o.resid = &h; o.out = h.p; o.out_ld = h.ld;  // h += out_proj(attn), in place
       conv_fwd(c, *Lw.o, a, nullptr, o);
       Act n2 = layernorm_fwd(c, Lw.ln2, h);
-      ConvOpts f1; f1.pad = 0; f1.act = ACT_QGELU;
+      ConvOpts f1; f1.pad = 0; f1.act = act_;
       Act g = conv_fwd(c, *Lw.fc1, n2, nullptr, f1);
       ConvOpts f2; f2.pad = 0; f2.resid = &h; f2.out = h.p; f2.out_ld = h.ld;  // h += fc2(quick_gelu(fc1))
       conv_fwd(c, *Lw.fc2, g, nullptr, f2);
@@ -129,7 +165,8 @@ class ClipText : public TextEncoder {
   }
 
  private:
-  int width_ = 0, layers_n_ = 0, heads_ = 0, mlp_ = 0, vocab_ = 0, maxpos_ = 0;
+  bool xtr_ = false;
+  int width_ = 0, layers_n_ = 0, heads_ = 0, mlp_ = 0, vocab_ = 0, maxpos_ = 0, inner_ = 0, causal_ = 1, act_ = ACT_QGELU;
   float *tok_ = nullptr, *pos_ = nullptr;
   std::vector<ClipLayer> layers_;
   LNW final_;

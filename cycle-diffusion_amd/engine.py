@@ -63,6 +63,13 @@ def clip_text_desc(width=768, layers=12, heads=12, mlp=3072, vocab=49408, positi
                      context_dim=mlp)
 
 
+def bert_xtransformer_desc(width=1280, layers=32, vocab=30522, positions=77, heads=8, dim_head=64):
+    """BERTEmbedder(n_embed=1280, n_layer=32) of txt2img-1p4B-eval.yaml: x-transformers Encoder (8 heads x 64, FF x4)"""
+    return make_desc(_ffi.CD_NET_BERT_XTR, image_size=positions, in_channels=vocab, out_channels=width,
+                     model_channels=width, num_res_blocks=layers, channel_mult=(1,), num_heads=heads,
+                     num_head_channels=dim_head, context_dim=4 * width)
+
+
 def afhq_iddpm_desc(image_size=256):
     """improved_ddpm/script_util.py:5-22,45-104 (AFHQ_DICT; learn_sigma -> 6 output channels)"""
     return make_desc(_ffi.CD_NET_UNET_OPENAI, image_size=image_size, in_channels=3, out_channels=6,

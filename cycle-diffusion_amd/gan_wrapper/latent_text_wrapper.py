@@ -79,6 +79,11 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
             from .text_encoders import FrozenCLIPEmbedderHIP
             assert udesc.context_dim == 768, "the CLIP ViT-L/14 text encoder conditions the SD-v1 U-Net"
             cond_stage = FrozenCLIPEmbedderHIP(self.engine)
+        elif cond_stage is None and text_encoder == "bert":
+            # `[gan] text_encoder = bert`: BERTEmbedder of LDM text2img-large (1280-wide contexts)
+            from .text_encoders import BERTEmbedderHIP
+            assert udesc.context_dim == 1280, "the BERT / x-transformer encoder conditions the LDM text2img U-Net"
+            cond_stage = BERTEmbedderHIP(self.engine)
         self.cond_stage = cond_stage or StandInTextEmbedder(udesc.context_dim)
         self.ranker = ranker
         self.alphas_cumprod = schedule.latent_alphas_cumprod(1000, self.LINEAR_START, self.LINEAR_END)

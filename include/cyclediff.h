@@ -27,7 +27,7 @@ extern "C" {
 
 typedef struct cd_engine* cd_handle;
 
-enum { CD_NET_UNET_OPENAI = 1, CD_NET_UNET_HO = 2, CD_NET_VAE_KL = 3, CD_NET_CLIP_TEXT = 4 };
+enum { CD_NET_UNET_OPENAI = 1, CD_NET_UNET_HO = 2, CD_NET_VAE_KL = 3, CD_NET_CLIP_TEXT = 4, CD_NET_BERT_XTR = 5 };
 enum { CD_SCHED_DDIM = 0, CD_SCHED_DDPM = 1 };
 
 /* Architecture descriptor (the hyper-parameters of the reference's YAML / dict configs):
@@ -38,7 +38,11 @@ enum { CD_SCHED_DDIM = 0, CD_SCHED_DDPM = 1 };
  *   CLIP_TEXT   : the HF `CLIPTextModel` behind FrozenCLIPEmbedder (ldm/modules/encoders/modules.py:136-161);
  *                 descriptor fields reused: model_channels = width (768), num_res_blocks = layers (12),
  *                 num_heads (12), context_dim = MLP width (3072), in_channels = vocabulary (49408),
- *                 image_size = positions (77); weights keyed by `text_model.*` (HF state_dict names) */
+ *                 image_size = positions (77); weights keyed by `text_model.*` (HF state_dict names)
+ *   BERT_XTR    : BERTEmbedder.transformer, the x-transformers TransformerWrapper(Encoder(dim 1280, depth 32)) of
+ *                 LDM text2img (model/lib/latentdiff/ldm/modules/encoders/modules.py:75-98); same fields plus
+ *                 num_head_channels = dim_head (64; heads 8 -> inner 512); weights keyed by `token_emb`,
+ *                 `pos_emb.emb`, `attn_layers.layers.*`, `norm` */
 typedef struct cd_net_desc {
   int kind;
   int image_size;          /* spatial size of the network input (latent 64, pixel 256, ...)      */
@@ -96,7 +100,8 @@ int cd_unet_forward(cd_handle h, int net, const float* x, const float* t, const 
 
 /* c = FrozenCLIPEmbedder(text): last_hidden_state of the CLIP text transformer for already tokenised text
  * (modules.py:148-158: tokenizer(..., max_length=77, padding="max_length") then transformer(input_ids)).
- * tokens [B,L] int32 (device), out [B,L,width] fp32 - the `ctx` tensors of the sampler entry points. */
+ * tokens [B,L] int32 (device), out [B,L,width] fp32 - the `ctx` tensors of the sampler entry points.
+ * For a BERT_XTR net: BERTEmbedder.forward (tokens -> transformer(tokens, return_embeddings=True)). */
 int cd_text_encode(cd_handle h, int net, const int32_t* tokens, int B, int L, float* out);
 
 /* z0 = scale * posterior(E(img)).sample() (or .mode() when sample==0) — encode_first_stage +

@@ -217,11 +217,29 @@ def gen_c1():
              z_norms=z25.flatten(2).norm(dim=2), img=out2)
 
 
+def gen_xtr_text():
+    """LDM text encoder: the reference's vendored x-transformers TransformerWrapper on seeded weights / ids."""
+    ref_import.setup()
+    sys.path.insert(0, os.path.join(ref_import.REF, "model", "lib", "latentdiff"))
+    from ldm.modules.x_transformer import Encoder, TransformerWrapper
+    from oracle import xtr_text
+    cfg = xtr_text.XtrTextCfg(width=64, layers=2, vocab=300, positions=77)
+    m = TransformerWrapper(num_tokens=cfg.vocab, max_seq_len=cfg.positions,
+                           attn_layers=Encoder(dim=cfg.width, depth=cfg.layers), emb_dropout=0.0).eval()
+    sd = xtr_text.synth_state_dict(cfg, 17)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("to_logits") for k in missing), (missing, unexpected)
+    ids = torch.randint(0, cfg.vocab, (3, 77), generator=torch.Generator().manual_seed(18))
+    with torch.no_grad():
+        y = m(ids, return_embeddings=True)
+    save("xtr_text_tiny", y=y, ids=ids, wseed=17, width=cfg.width, layers=cfg.layers, vocab=cfg.vocab)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    todo = dict(schedule=gen_schedule, nets=gen_nets, latent=gen_latent_cycle, c1=gen_c1)
+    todo = dict(schedule=gen_schedule, nets=gen_nets, latent=gen_latent_cycle, c1=gen_c1, xtr=gen_xtr_text)
     for k, fn in todo.items():
         if not a.only or a.only == k:
             fn()

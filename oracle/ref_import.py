@@ -24,6 +24,10 @@ def available():
 
 def _stub(name, **attrs):
     m = types.ModuleType(name)
+    # a real spec: other libraries (transformers) probe optional packages with importlib.util.find_spec,
+    # which raises on a module whose __spec__ is None
+    import importlib.machinery
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
     for k, v in attrs.items():
         setattr(m, k, v)
     sys.modules[name] = m

@@ -7,6 +7,7 @@ import torch
 import cycle_diffusion_amd as cda
 from cycle_diffusion_amd import _ffi
 from oracle import clip_text as oc
+from oracle import xtr_text as ox
 
 pytestmark = pytest.mark.gpu
 
@@ -52,3 +53,40 @@ def test_frozen_clip_embedder_on_engine(engine):
     assert c.shape == (3, 77, 768) and torch.isfinite(c).all()
     # causal transformer: the first token's state cannot depend on the text; later ones do
     assert torch.equal(c[0, 0], c[1, 0]) and not torch.equal(c[0, 5], c[1, 5])
+
+
+# ------------------------------------------------------------------ LDM text encoder (BERTEmbedder.transformer)
+def _run_xtr(engine, cfg, B, L, seed):
+    net = engine.create_net(cda.bert_xtransformer_desc(cfg.width, cfg.layers, cfg.vocab, cfg.positions, cfg.heads,
+                                                       cfg.dim_head))
+    assert set(n for n, _ in engine.net_params(net)) == set(n for n, _ in ox.param_shapes(cfg))
+    sd = ox.synth_state_dict(cfg, seed)
+    n, first = engine.load_state_dict(net, sd)
+    assert n == 0, first
+    ids = torch.randint(0, cfg.vocab, (B, L), generator=torch.Generator().manual_seed(seed + 1))
+    with torch.no_grad():
+        ref = ox.xtr_text_forward(sd, cfg, ids)
+    got = engine.text_encode(net, ids).cpu()
+    d = (got - ref).abs()
+    return d.max().item() / ref.abs().max().item(), d.mean().item() / ref.abs().mean().item()
+
+
+def test_bert_xtransformer_small(engine, report):
+    rmax, rmean = _run_xtr(engine, ox.XtrTextCfg(width=128, layers=3, vocab=500, positions=77), 3, 77, 21)
+    report.add("xtr_text/small", rel_to_max=rmax, mean_rel=rmean)
+    assert rmax < 8e-3 * FMT and rmean < 8e-3 * FMT, (rmax, rmean)
+
+
+def test_bert_xtransformer_ldm_width(engine, report):
+    """Width 1280 as in txt2img-1p4B-eval.yaml (BERTEmbedder n_embed 1280), 4 of the 32 layers: every layer has
+    the same shapes, the depth only repeats them."""
+    rmax, rmean = _run_xtr(engine, ox.XtrTextCfg(width=1280, layers=4, vocab=30522, positions=77), 2, 77, 22)
+    report.add("xtr_text/w1280", rel_to_max=rmax, mean_rel=rmean)
+    assert rmax < 8e-3 * FMT and rmean < 8e-3 * FMT, (rmax, rmean)
+
+
+def test_bert_embedder_on_engine(engine):
+    from cycle_diffusion_amd.gan_wrapper.text_encoders import BERTEmbedderHIP
+    emb = BERTEmbedderHIP(engine, layers=2)
+    c = emb(["a painting of a fox", ""])
+    assert c.shape == (2, 77, 1280) and torch.isfinite(c).all()
