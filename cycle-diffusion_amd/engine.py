@@ -96,7 +96,9 @@ class Engine:
         torch.cuda.set_device(self.device)
         if workspace_bytes is None:
             free, _total = torch.cuda.mem_get_info(self.device)
-            workspace_bytes = int(min(96 << 30, free * 0.45))
+            # the bump arena is reserved up front: 32 GB covers the largest folded-ensemble VAE decode (32 images
+            # at 512x512) many times over and leaves room for several engines per GPU (bench.py replicas)
+            workspace_bytes = int(min(32 << 30, free * 0.45))
         self.stream = torch.cuda.current_stream(self.device)
         h = C.c_void_p()
         check(self.lib.cd_engine_create(C.c_void_p(self.stream.cuda_stream), C.c_size_t(workspace_bytes), C.byref(h)))
