@@ -273,13 +273,23 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
     };
     // segment 0: fragments of the first two k-slices; then per k-slice one pinned segment with its share
     // of the staging loads, the slice's MFMAs (independent accumulators) and the reads two slices ahead
+    // 2-deep rings: the refill of the slot just released goes out in one burst right after the barrier, so it has
+    // the whole step to land (+5 % on the 128x64 / 128x128 s2 tiles); deeper rings have a step of slack already
+    // and do better with the loads spread over the MFMA segments (a burst costs them 8 %)
+    constexpr bool front = (NSTAGE == 2);
+    if (front) {
+#pragma unroll
+      for (int l = 0; l < LPT; ++l) issue(l, nxt);
+    }
     read_frags(0);
     if (KS > 1) read_frags(1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
+      if (!front) {
 #pragma unroll
       for (int l = (ks * LPT) / KS; l < ((ks + 1) * LPT) / KS; ++l) issue(l, nxt);
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
