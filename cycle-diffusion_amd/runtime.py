@@ -16,6 +16,9 @@ def get_engine(device=None):
     if device is None:
         device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
     dev = torch.device(device)
+    if not torch.cuda.is_available():
+        from ._ffi import EngineError
+        raise EngineError("no HIP device visible to PyTorch: the CycleDiffusion engine has no CPU fallback")
     key = (str(dev), int(torch.cuda.current_stream(dev).cuda_stream))
     if key not in _ENGINES:
         _ENGINES[key] = Engine(str(dev))

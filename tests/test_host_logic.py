@@ -1,0 +1,89 @@
+"""Host-side logic that needs no GPU: config parsing (utils/config_utils.py contract), the [gan] -> kwargs
+remapping of get_gan_wrapper (model/gan_wrapper/get_gan_wrapper.py:3-30), ensemble grouping, the stand-in
+tokenizers' framing, and that the product path refuses to run without a HIP device."""
+import os
+import types
+
+import pytest
+import torch
+
+import cycle_diffusion_amd  # noqa: F401
+from cycle_diffusion_amd.gan_wrapper import get_gan_wrapper as ggw
+from cycle_diffusion_amd.gan_wrapper.latent_text_wrapper import _LatentStochasticTextWrapper
+from cycle_diffusion_amd.gan_wrapper.text_encoders import BOS, EOS, BertHashTokenizer, HashTokenizer
+from cycle_diffusion_amd.utils.config_utils import get_config, parse_string
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_parse_string_casts_like_the_reference():
+    assert parse_string("99") == 99 and isinstance(parse_string("99"), int)
+    assert parse_string("0.1") == 0.1
+    assert parse_string("True") is True and parse_string("false") is False and parse_string("None") is None
+    assert parse_string("[0, 10]") == [0, 10]
+    assert parse_string('"sd-v1-4.ckpt"') == "sd-v1-4.ckpt" and parse_string("sd-v1-4.ckpt") == "sd-v1-4.ckpt"
+
+
+def test_bench_config_is_the_c2_gan_section():
+    args = get_config("experiments/bench_sd_c2.cfg", config_root=os.path.join(ROOT, "config"))
+    assert args.model.name == "text_unsupervised_translation"
+    gan = dict(iter(args.gan))
+    assert gan["gan_type"] == "SDStochasticText" and gan["custom_steps"] == 99 and gan["white_box_steps"] == 100
+    assert gan["eta"] == 0.1 and gan["skip_steps"] == [0] and gan["n_trials"] == 1
+    assert gan["encoder_unconditional_guidance_scales"] == [1] and gan["decoder_unconditional_guidance_scales"] == [3]
+    assert args.gan.not_a_key is None  # unknown attributes read as None
+    assert list(k for k, _ in args.gan) == sorted(gan)  # iteration order: sorted keys
+
+
+def test_get_gan_wrapper_kwarg_remapping(monkeypatch):
+    seen = {}
+
+    class Fake:
+        def __init__(self, **kw):
+            seen.update(kw)
+
+    fake_mod = types.SimpleNamespace(DDPMDDIMWrapper=Fake)
+    monkeypatch.setitem(__import__("sys").modules, "cycle_diffusion_amd.gan_wrapper.ddpm_ddim_wrapper", fake_mod)
+
+    class A:  # minimal stand-in for the parsed [gan] section
+        gan_type = "DDPM_DDIM"
+        items = [("custom_steps", 50), ("gan_type", "DDPM_DDIM"), ("sample_type", "ddim"),
+                 ("source_model_type", "cat"), ("target_model_type", "dog")]
+
+        def __iter__(self):
+            return iter(self.items)
+
+    ggw.get_gan_wrapper(A(), target=False)
+    assert seen == {"custom_steps": 50, "sample_type": "ddim", "source_model_type": "cat"}
+    seen.clear()
+    ggw.get_gan_wrapper(A(), target=True)  # target_* keys are renamed to source_*; source_* dropped
+    assert seen == {"custom_steps": 50, "sample_type": "ddim", "source_model_type": "dog"}
+
+
+def test_ensemble_grouping_preserves_first_appearance_order():
+    w = types.SimpleNamespace(fold_ensemble=True)
+    keys = [(1.0, 0), (1.0, 4), (1.0, 0), (3.0, 0), (1.0, 4)]
+    assert _LatentStochasticTextWrapper._groups(w, keys) == [[0, 2], [1, 4], [3]]
+    w.fold_ensemble = False
+    assert _LatentStochasticTextWrapper._groups(w, keys) == [[0], [1], [2], [3], [4]]
+
+
+def test_stand_in_tokenizers_keep_the_reference_framing():
+    ids = HashTokenizer()(["a photo of a cat", "", "A Photo"])
+    assert ids.shape == (3, 77) and ids.dtype == torch.int32
+    assert ids[0, 0] == BOS and ids[0, 6] == EOS and (ids[0, 6:] == EOS).all()
+    assert ids[1, 0] == BOS and ids[1, 1] == EOS
+    assert ids[0, 1] == ids[2, 1] and ids[0, 2] == ids[2, 2]  # case-insensitive, one stable id per word
+    assert ((ids > 0) & (ids < 49408)).all()
+    b = BertHashTokenizer()(["hello world", ""])
+    assert b[0, 0] == 101 and b[0, 3] == 102 and (b[0, 4:] == 0).all() and b[1, 1] == 102
+    long = HashTokenizer()([" ".join(["w%d" % i for i in range(200)])])
+    assert long[0, 76] == EOS and long[0, 75] != EOS  # truncated to 75 words + BOS/EOS
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only check")
+def test_wrappers_refuse_to_run_without_a_gpu():
+    from cycle_diffusion_amd import _ffi
+    from cycle_diffusion_amd.gan_wrapper.ddpm_ddim_wrapper import DDPMDDIMWrapper
+    with pytest.raises(_ffi.EngineError):
+        DDPMDDIMWrapper(source_model_type="toy32", sample_type="ddpm", custom_steps=4, es_steps=4)
