@@ -126,7 +126,7 @@ def test_latent_cycle_tiny(engine, report):
     cyc = (x_same.cpu() - x0).abs().max().item()
     report.add("sampler/latent_cycle_maxabs", err=cyc, reference=float(fx["cycle_err"]))
     # the engine's U-Net is deterministic, so its own cycle closes to fp32 round-off of the scheduler math
-    assert cyc < 5e-3, cyc
+    assert cyc < 8e-3 * FMT, cyc  # measured 2.2e-3 .. 3.0e-3 across runs (tile choices vary the rounding)
     x_tgt = engine.ddim_decode(net, _ffi.CD_SCHED_DDIM, z, coef_d, ctx_c=c2.cuda(), ctx_uc=uc.cuda(), guidance=3.0)
     _check(report, "sampler/latent_x_tgt", x_tgt, fx["x_tgt"], rel=3e-2 * FMT, mean=1.5e-2 * FMT)  # measured 6e-3 / 3e-3
 
