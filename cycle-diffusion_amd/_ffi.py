@@ -98,6 +98,8 @@ def load_library(build_if_missing=True):
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         mod.build()
+    # tile / split-K choices for the reference networks' GEMM shapes, measured once on MI355X (conv_gemm.hip)
+    os.environ.setdefault("CYCLEDIFF_TUNE_DEFAULT", os.path.join(_HERE, "tune_gfx950.txt"))
     # CYCLEDIFF_LIB: A/B timing of two builds of the SAME ABI on one box (scripts/); never a CPU fallback
     lib = C.CDLL(os.environ.get("CYCLEDIFF_LIB") or LIB_PATH)
     for name, args in SIGNATURES.items():
