@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcyclediff.so")
 
 CD_NET_UNET_OPENAI, CD_NET_UNET_HO, CD_NET_VAE_KL, CD_NET_CLIP_TEXT, CD_NET_BERT_XTR = 1, 2, 3, 4, 5
+CD_NET_OCLIP_TEXT, CD_NET_OCLIP_VISION = 6, 7
 CD_SCHED_DDIM, CD_SCHED_DDPM = 0, 1
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
 
@@ -59,6 +60,8 @@ SIGNATURES = {
     "cd_net_missing_params": [_VP, _I, C.POINTER(_I), C.c_char_p, _I],
     "cd_unet_forward": [_VP, _I, _VP, _VP, _VP, _I, _I, _VP],
     "cd_text_encode": [_VP, _I, _VP, _I, _I, _VP],
+    "cd_clip_text_features": [_VP, _I, _VP, _I, _I, _VP],
+    "cd_clip_image_features": [_VP, _I, _VP, _I, _VP],
     "cd_vae_encode": [_VP, _I, _VP, _VP, _U64, _I, _I, _I, _F, _VP],
     "cd_vae_decode": [_VP, _I, _VP, _I, _I, _F, _F, _F, _VP],
     "cd_dpm_encode": [_VP, _I, _I, _VP, _VP, _VP, _I, _F, _I, _I, _VP, _VP, _U64, _I, _VP],

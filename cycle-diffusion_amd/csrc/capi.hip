@@ -160,7 +160,9 @@ int cd_net_create(cd_handle h, const cd_net_desc* d, int* net_id) {
     case CD_NET_UNET_HO: n = make_unet_ho(*d); break;
     case CD_NET_VAE_KL: n = make_vae_kl(*d); break;
     case CD_NET_CLIP_TEXT:
-    case CD_NET_BERT_XTR: n = make_clip_text(*d); break;
+    case CD_NET_BERT_XTR:
+    case CD_NET_OCLIP_TEXT:
+    case CD_NET_OCLIP_VISION: n = make_clip_text(*d); break;
     default: CD_CHECK(false, "unknown net kind %d", d->kind);
   }
   h->nets.push_back(std::move(n));
@@ -329,6 +331,29 @@ int cd_text_encode(cd_handle h, int net, const int32_t* tokens, int B, int L, fl
   CD_CHECK(tokens && out && B > 0 && L > 0, "bad argument");
   Ctx c = h->ctx();
   static_cast<TextEncoder*>(h->nets[net].get())->encode(c, (const int*)tokens, B, L, out);
+  CD_API_END
+}
+
+static TextEncoder* get_tower(cd_handle h, int net, int kind) {
+  CD_CHECK(h && net >= 0 && net < (int)h->nets.size() && h->nets[net]->kind() == kind, "net %d has the wrong kind", net);
+  return static_cast<TextEncoder*>(h->nets[net].get());
+}
+
+int cd_clip_text_features(cd_handle h, int net, const int32_t* tokens, int B, int L, float* out) {
+  CD_API_BEGIN
+  enter_engine(h);
+  CD_CHECK(tokens && out && B > 0 && L > 0, "bad argument");
+  Ctx c = h->ctx();
+  get_tower(h, net, CD_NET_OCLIP_TEXT)->text_features(c, (const int*)tokens, B, L, out);
+  CD_API_END
+}
+
+int cd_clip_image_features(cd_handle h, int net, const float* img, int B, float* out) {
+  CD_API_BEGIN
+  enter_engine(h);
+  CD_CHECK(img && out && B > 0, "bad argument");
+  Ctx c = h->ctx();
+  get_tower(h, net, CD_NET_OCLIP_VISION)->image_features(c, img, B, out);
   CD_API_END
 }
 

@@ -152,6 +152,42 @@ __global__ void k_embed_tokens(const int* __restrict__ ids, const float* __restr
   }
 }
 
+__global__ void k_vit_tokens(const bf16_t* __restrict__ patch, const float* __restrict__ cls,
+                             const float* __restrict__ pos, bf16_t* __restrict__ out, int B, int T, int D) {
+  const int nvec = D / 8;
+  const int64_t n = (int64_t)B * (T + 1) * nvec;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int v = (int)(i % nvec);
+    const int64_t bt = i / nvec;
+    const int t = (int)(bt % (T + 1));
+    const int b = (int)(bt / (T + 1));
+    float f[8];
+    if (t == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = cls[v * 8 + e];
+    } else {
+      unpack8(*(const uint4*)(patch + ((int64_t)b * T + (t - 1)) * D + v * 8), f);
+    }
+    const float* pr = pos + (int64_t)t * D + v * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] += pr[e];
+    *(uint4*)(out + bt * D + v * 8) = pack8(f);
+  }
+}
+
+// x[b, argmax(ids[b])] (model.py encode_text: x[torch.arange(B), text.argmax(dim=-1)]; first maximum on ties)
+__global__ void k_gather_eot(const bf16_t* __restrict__ x, const int* __restrict__ ids, bf16_t* __restrict__ out,
+                             int L, int D) {
+  const int b = blockIdx.x;
+  int best = 0, bv = ids[(int64_t)b * L];
+  for (int l = 1; l < L; ++l) {
+    const int v = ids[(int64_t)b * L + l];
+    if (v > bv) { bv = v; best = l; }
+  }
+  const bf16_t* src = x + ((int64_t)b * L + best) * D;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) out[(int64_t)b * D + i] = src[i];
+}
+
 __global__ void k_avgpool2(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int C) {
   const int Ho = H / 2, Wo = W / 2, nvec = C / 8;
   const int64_t n = (int64_t)B * Ho * Wo * nvec;
@@ -285,6 +321,15 @@ void launch_embed_tokens(hipStream_t st, const int* ids, const float* tok, const
   CD_CHECK(D % 8 == 0, "embed_tokens: width %% 8");
   const int64_t n = (int64_t)B * L * (D / 8);
   hipLaunchKernelGGL(k_embed_tokens, dim3(ew_grid(n)), dim3(256), 0, st, ids, tok, pos, out, B, L, D, vocab);
+}
+void launch_vit_tokens(hipStream_t st, const bf16_t* patch, const float* cls, const float* pos, bf16_t* out, int B,
+                       int T, int D) {
+  CD_CHECK(D % 8 == 0, "vit_tokens: width %% 8");
+  const int64_t n = (int64_t)B * (T + 1) * (D / 8);
+  hipLaunchKernelGGL(k_vit_tokens, dim3(ew_grid(n)), dim3(256), 0, st, patch, cls, pos, out, B, T, D);
+}
+void launch_gather_eot(hipStream_t st, const bf16_t* x, const int* ids, bf16_t* out, int B, int L, int D) {
+  hipLaunchKernelGGL(k_gather_eot, dim3(B), dim3(256), 0, st, x, ids, out, L, D);
 }
 void launch_fill_f32(hipStream_t st, float* p, float v, int64_t n) {
   hipLaunchKernelGGL(k_fill_f32, dim3(ew_grid(n)), dim3(256), 0, st, p, v, n);

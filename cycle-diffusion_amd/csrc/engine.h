@@ -69,6 +69,7 @@ struct ParamDecl {
   std::vector<int64_t> shape;  // reference (torch) shape
   std::vector<PackTarget> targets;
   bool loaded = false;
+  bool transposed = false;  // reference tensor is [K][N] (used as x @ W); rows are transposed on load
 };
 
 class ParamStore {
@@ -81,6 +82,8 @@ class ParamStore {
   ParamDecl& declare(const std::string& name, std::vector<int64_t> shape);
   // whole tensor -> whole ConvW; ref_ndim = rank of the reference tensor (2 Linear, 3 Conv1d, 4 Conv2d; 0 = auto)
   void conv_weight(const std::string& name, ConvW* c, int ref_ndim = 0);
+  // reference tensor of shape [Cin][N] applied as `x @ W` (OpenAI CLIP `proj` / `text_projection`)
+  void conv_weight_t(const std::string& name, ConvW* c);
   void conv_bias(const std::string& name, ConvW* c);
   void conv_rows(const std::string& name, std::vector<int64_t> shape, ConvW* c, int dst_row0, int rows,
                  int src_base, int grp, int grp_stride);
@@ -197,6 +200,9 @@ std::unique_ptr<VAE> make_vae_kl(const cd_net_desc& d);
 class TextEncoder : public Net {  // token ids -> conditioning sequence
  public:
   virtual void encode(Ctx& c, const int* ids_dev, int B, int L, float* out) = 0;  // fp32 [B][L][width]
+  // OpenAI-CLIP towers (DirectionalCLIP ranker): pooled + projected features fp32 [B][embed]
+  virtual void text_features(Ctx&, const int*, int, int, float*) { CD_CHECK(false, "net has no pooled text features"); }
+  virtual void image_features(Ctx&, const float*, int, float*) { CD_CHECK(false, "net has no image tower"); }
   virtual int width() const = 0;
   virtual int max_positions() const = 0;
 };

@@ -75,6 +75,14 @@ void ParamStore::conv_weight(const std::string& name, ConvW* c, int ref_ndim) {
   t.src_base = 0; t.grp = c->N; t.grp_stride = 0; t.geglu = c->geglu;
   d.targets.push_back(t);
 }
+void ParamStore::conv_weight_t(const std::string& name, ConvW* c) {
+  CD_CHECK(c->KH == 1 && c->KW == 1, "transposed weights are linear layers");
+  ParamDecl& d = declare(name, {c->Cin, c->N});
+  d.transposed = true;
+  PackTarget t; t.kind = PackTarget::MATRIX_BF16; t.conv = c; t.dst_row0 = 0; t.rows = c->N;
+  t.src_base = 0; t.grp = c->N; t.grp_stride = 0; t.geglu = false;
+  d.targets.push_back(t);
+}
 void ParamStore::conv_bias(const std::string& name, ConvW* c) {
   CD_CHECK(c->b, "conv %s has no bias storage", name.c_str());
   ParamDecl& d = declare(name, {c->N});
@@ -150,7 +158,15 @@ void ParamStore::load(hipStream_t st, const std::string& name, const float* host
     HIP_CHECK(hipMalloc((void**)&staging_, staging_bytes_));
   }
   HIP_CHECK(hipStreamSynchronize(st));
-  HIP_CHECK(hipMemcpy(staging_, host, bytes, hipMemcpyHostToDevice));
+  if (d.transposed) {  // [K][N] -> [N][K] on the host (small projection matrices)
+    const int64_t K = d.shape[0], N = d.shape[1];
+    std::vector<float> tr((size_t)n);
+    for (int64_t k = 0; k < K; ++k)
+      for (int64_t j = 0; j < N; ++j) tr[(size_t)j * K + k] = host[(size_t)k * N + j];
+    HIP_CHECK(hipMemcpy(staging_, tr.data(), bytes, hipMemcpyHostToDevice));
+  } else {
+    HIP_CHECK(hipMemcpy(staging_, host, bytes, hipMemcpyHostToDevice));
+  }
   for (const PackTarget& t : d.targets) {
     if (t.kind == PackTarget::MATRIX_BF16) {
       const ConvW* c = t.conv;

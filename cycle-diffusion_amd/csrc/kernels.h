@@ -203,6 +203,11 @@ void launch_posterior_sample(hipStream_t st, const float* mom, int ld, const flo
                              uint64_t seed, float* z, int B, int zc, int HW, float scale,
                              int use_mean);
 void launch_fill_f32(hipStream_t st, float* p, float v, int64_t n);
+// ViT token assembly (OpenAI CLIP VisionTransformer.forward): out[b][0] = cls + pos[0]; out[b][1+t] = patch[b][t] + pos[1+t]
+void launch_vit_tokens(hipStream_t st, const bf16_t* patch, const float* cls, const float* pos, bf16_t* out, int B,
+                       int T, int D);
+// out[b][:] = x[b][argmax_l ids[b][l]][:]  (CLIP text pooling at the end-of-text token, the largest id)
+void launch_gather_eot(hipStream_t st, const bf16_t* x, const int* ids, bf16_t* out, int B, int L, int D);
 // token + position embedding lookup: out[b][l][:] = tok[ids[b][l]][:] + pos[l][:] (fp32 tables -> 16-bit rows)
 void launch_embed_tokens(hipStream_t st, const int* ids, const float* tok, const float* pos, bf16_t* out, int B,
                          int L, int D, int vocab);

@@ -63,6 +63,20 @@ def clip_text_desc(width=768, layers=12, heads=12, mlp=3072, vocab=49408, positi
                      context_dim=mlp)
 
 
+def oclip_text_desc(width=512, layers=12, heads=8, vocab=49408, positions=77, embed=512):
+    """text tower of OpenAI CLIP ViT-B/32 (clip/model.py CLIP.__init__: transformer_width 512, heads 8, layers 12)"""
+    return make_desc(_ffi.CD_NET_OCLIP_TEXT, image_size=positions, in_channels=vocab, out_channels=embed,
+                     model_channels=width, num_res_blocks=layers, channel_mult=(1,), num_heads=heads,
+                     context_dim=4 * width)
+
+
+def oclip_vision_desc(width=768, layers=12, heads=12, resolution=224, patch=32, embed=512):
+    """image tower of OpenAI CLIP ViT-B/32 (clip/model.py VisionTransformer: width 768, patch 32, 12 layers)"""
+    return make_desc(_ffi.CD_NET_OCLIP_VISION, image_size=resolution, in_channels=3, out_channels=embed,
+                     model_channels=width, num_res_blocks=layers, channel_mult=(1,), num_heads=heads,
+                     context_dim=4 * width, z_channels=patch)
+
+
 def bert_xtransformer_desc(width=1280, layers=32, vocab=30522, positions=77, heads=8, dim_head=64):
     """BERTEmbedder(n_embed=1280, n_layer=32) of txt2img-1p4B-eval.yaml: x-transformers Encoder (8 heads x 64, FF x4)"""
     return make_desc(_ffi.CD_NET_BERT_XTR, image_size=positions, in_channels=vocab, out_channels=width,
@@ -167,7 +181,8 @@ class Engine:
                 base = name.rsplit(".", 1)[0]
                 is_norm = name.endswith("weight") and (".norm" in name or "in_layers.0" in name or "out_layers.0" in name
                                                        or name.startswith("out.0") or "norm_out" in name
-                                                       or "layer_norm" in name)
+                                                       or "layer_norm" in name or ".ln_" in name
+                                                       or name.startswith("ln_"))
                 if is_norm:
                     t = 1.0 + 0.05 * torch.randn(shape, generator=g)
                 else:
@@ -203,6 +218,23 @@ class Engine:
         B, L = ids.shape
         out = torch.empty((B, L, self._descs[net].model_channels), device=self.device, dtype=torch.float32)
         check(self.lib.cd_text_encode(self.h, net, ptr(ids), B, L, ptr(out)))
+        return out
+
+    def clip_text_features(self, net, tokens):
+        """model.encode_text(tokens) of OpenAI CLIP: [B, L] ids -> [B, embed] fp32 (un-normalised)."""
+        ids = tokens.to(device=self.device, dtype=torch.int32).contiguous()
+        B, L = ids.shape
+        out = torch.empty((B, self._descs[net].out_channels), device=self.device, dtype=torch.float32)
+        check(self.lib.cd_clip_text_features(self.h, net, ptr(ids), B, L, ptr(out)))
+        return out
+
+    def clip_image_features(self, net, img):
+        """model.encode_image(img) of OpenAI CLIP: preprocessed [B, 3, R, R] fp32 -> [B, embed] fp32."""
+        img = self._f32(img)
+        d = self._descs[net]
+        assert img.shape[1:] == (3, d.image_size, d.image_size), img.shape
+        out = torch.empty((img.shape[0], d.out_channels), device=self.device, dtype=torch.float32)
+        check(self.lib.cd_clip_image_features(self.h, net, ptr(img), img.shape[0], ptr(out)))
         return out
 
     def vae_encode(self, net, img, noise=None, seed=0, sample=True, scale=0.18215):

@@ -85,6 +85,9 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
             assert udesc.context_dim == 1280, "the BERT / x-transformer encoder conditions the LDM text2img U-Net"
             cond_stage = BERTEmbedderHIP(self.engine)
         self.cond_stage = cond_stage or StandInTextEmbedder(udesc.context_dim)
+        if ranker == "directional_clip":  # `[gan] ranker = directional_clip`: the reference's DirectionalCLIP on the engine
+            from .ranker import DirectionalCLIPHIP
+            ranker = DirectionalCLIPHIP(self.engine)
         self.ranker = ranker
         self.alphas_cumprod = schedule.latent_alphas_cumprod(1000, self.LINEAR_START, self.LINEAR_END)
         # `next(self.parameters()).device` must work (sd_wrapper:251-253) and DDP must be able to wrap us
@@ -201,7 +204,10 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
                 "ensemble of %d candidates needs a DirectionalCLIP ranker (model/energy/clean_clip.py) — out of "
                 "scope for the hot path; pass ranker=callable(img, original_img, encode_text, decode_text)"
                 % len(img_ensemble))
-        scores = torch.stack([self.ranker(img, original_img, encode_text, decode_text) for img in img_ensemble], dim=1)
+        def score(img):  # DirectionalCLIP returns (clip_score, dclip_score) and the reference ranks by the latter
+            r = self.ranker(img, original_img, encode_text, decode_text)
+            return r[1] if isinstance(r, (tuple, list)) else r
+        scores = torch.stack([score(img) for img in img_ensemble], dim=1)
         best = torch.argmax(scores, dim=1)  # per-sample argmax over the ensemble (sd_wrapper:228-235)
         return torch.stack([img_ensemble[best[b].item()][b] for b in range(scores.shape[0])], dim=0)
 

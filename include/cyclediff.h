@@ -27,7 +27,8 @@ extern "C" {
 
 typedef struct cd_engine* cd_handle;
 
-enum { CD_NET_UNET_OPENAI = 1, CD_NET_UNET_HO = 2, CD_NET_VAE_KL = 3, CD_NET_CLIP_TEXT = 4, CD_NET_BERT_XTR = 5 };
+enum { CD_NET_UNET_OPENAI = 1, CD_NET_UNET_HO = 2, CD_NET_VAE_KL = 3, CD_NET_CLIP_TEXT = 4, CD_NET_BERT_XTR = 5,
+       CD_NET_OCLIP_TEXT = 6, CD_NET_OCLIP_VISION = 7 };
 enum { CD_SCHED_DDIM = 0, CD_SCHED_DDPM = 1 };
 
 /* Architecture descriptor (the hyper-parameters of the reference's YAML / dict configs):
@@ -42,7 +43,11 @@ enum { CD_SCHED_DDIM = 0, CD_SCHED_DDPM = 1 };
  *   BERT_XTR    : BERTEmbedder.transformer, the x-transformers TransformerWrapper(Encoder(dim 1280, depth 32)) of
  *                 LDM text2img (model/lib/latentdiff/ldm/modules/encoders/modules.py:75-98); same fields plus
  *                 num_head_channels = dim_head (64; heads 8 -> inner 512); weights keyed by `token_emb`,
- *                 `pos_emb.emb`, `attn_layers.layers.*`, `norm` */
+ *                 `pos_emb.emb`, `attn_layers.layers.*`, `norm`
+ *   OCLIP_TEXT / OCLIP_VISION : the text and image towers of OpenAI CLIP (ViT-B/32 in the reference:
+ *                 model/energy/clean_clip.py:10 `clip.load("ViT-B/32")`), weights keyed by the openai/CLIP package's
+ *                 state_dict names; out_channels = embedding width (512); VISION: image_size = input resolution
+ *                 (224), z_channels = patch size (32), in_channels = 3 */
 typedef struct cd_net_desc {
   int kind;
   int image_size;          /* spatial size of the network input (latent 64, pixel 256, ...)      */
@@ -103,6 +108,12 @@ int cd_unet_forward(cd_handle h, int net, const float* x, const float* t, const 
  * tokens [B,L] int32 (device), out [B,L,width] fp32 - the `ctx` tensors of the sampler entry points.
  * For a BERT_XTR net: BERTEmbedder.forward (tokens -> transformer(tokens, return_embeddings=True)). */
 int cd_text_encode(cd_handle h, int net, const int32_t* tokens, int B, int L, float* out);
+
+/* DirectionalCLIP's feature extractors (model/energy/clean_clip.py:24-31): model.encode_text(tokens) and
+ * model.encode_image(preprocessed) of OpenAI CLIP, un-normalised. tokens [B,L] int32; img [B,3,R,R] fp32 already
+ * resized / centre-cropped / mean-std normalised; out [B,embed] fp32. */
+int cd_clip_text_features(cd_handle h, int net, const int32_t* tokens, int B, int L, float* out);
+int cd_clip_image_features(cd_handle h, int net, const float* img, int B, float* out);
 
 /* z0 = scale * posterior(E(img)).sample() (or .mode() when sample==0) — encode_first_stage +
  * get_first_stage_encoding (ddpm.py:817-854, 536-543); img [B,3,R,R] in [-1,1]; noise [B,zc,R/8,R/8]

@@ -90,3 +90,65 @@ def test_bert_embedder_on_engine(engine):
     emb = BERTEmbedderHIP(engine, layers=2)
     c = emb(["a painting of a fox", ""])
     assert c.shape == (2, 77, 1280) and torch.isfinite(c).all()
+
+
+# ------------------------------------------------------------------ OpenAI CLIP towers + DirectionalCLIP ranker
+def _oclip_nets(engine, cfg, seed):
+    from oracle import openai_clip as ocl
+    tnet = engine.create_net(cda.oclip_text_desc(cfg.t_width, cfg.t_layers, cfg.t_heads, cfg.vocab, cfg.positions, cfg.embed))
+    vnet = engine.create_net(cda.oclip_vision_desc(cfg.v_width, cfg.v_layers, cfg.v_heads, cfg.res, cfg.patch, cfg.embed))
+    assert set(n for n, _ in engine.net_params(tnet)) == set(n for n, _ in ocl.text_shapes(cfg))
+    assert set(n for n, _ in engine.net_params(vnet)) == set(n for n, _ in ocl.vision_shapes(cfg))
+    sd = {**ocl.synth_state_dict(ocl.vision_shapes(cfg), seed), **ocl.synth_state_dict(ocl.text_shapes(cfg), seed + 1)}
+    for net in (tnet, vnet):
+        n, first = engine.load_state_dict(net, sd)
+        assert n == 0, first
+    return tnet, vnet, sd
+
+
+def _feat_err(got, ref):
+    d = (got.cpu() - ref).abs()
+    return d.max().item() / ref.abs().max().item()
+
+
+def test_openai_clip_towers_small(engine, report):
+    from oracle import openai_clip as ocl
+    cfg = ocl.OClipCfg(embed=64, res=64, patch=16, v_width=128, v_layers=2, v_heads=2, t_width=64, t_layers=2, t_heads=1,
+                       vocab=400, positions=24)
+    tnet, vnet, sd = _oclip_nets(engine, cfg, 51)
+    g = torch.Generator().manual_seed(52)
+    img = torch.randn(3, 3, 64, 64, generator=g)
+    ids = torch.randint(1, cfg.vocab - 1, (3, 24), generator=g)
+    for b, pos in enumerate((5, 23, 11)):
+        ids[b, pos] = cfg.vocab - 1
+        ids[b, pos + 1:] = 0
+    with torch.no_grad():
+        ri, rt = ocl.encode_image(sd, cfg, img), ocl.encode_text(sd, cfg, ids)
+    ei = _feat_err(engine.clip_image_features(vnet, img.cuda()), ri)
+    et = _feat_err(engine.clip_text_features(tnet, ids), rt)
+    report.add("oclip/small", image_rel=ei, text_rel=et)
+    assert ei < 8e-3 * FMT and et < 8e-3 * FMT, (ei, et)
+
+
+def test_openai_clip_vit_b32_and_directional_scores(engine, report):
+    """Full ViT-B/32 configuration (both towers) and the ranker's scores on 512x512 images vs the oracle."""
+    from cycle_diffusion_amd.gan_wrapper.ranker import DirectionalCLIPHIP, clip_preprocess
+    from oracle import openai_clip as ocl
+    cfg = ocl.OClipCfg()
+    sd = {**ocl.synth_state_dict(ocl.vision_shapes(cfg), 61), **ocl.synth_state_dict(ocl.text_shapes(cfg), 62)}
+    rk = DirectionalCLIPHIP(engine, state_dict=sd)
+    g = torch.Generator().manual_seed(63)
+    img, orig = torch.rand(2, 3, 512, 512, generator=g), torch.rand(2, 3, 512, 512, generator=g)
+    src, tgt = ["a photo of a cat", "a red car"], ["a photo of a dog", "a blue car"]
+    assert torch.allclose(clip_preprocess(img), ocl.preprocess(img), atol=1e-6)
+    cs, ds = rk(img.cuda(), orig.cuda(), src, tgt)
+    with torch.no_grad():
+        fi, fo = ocl.encode_image(sd, cfg, ocl.preprocess(img)), ocl.encode_image(sd, cfg, ocl.preprocess(orig))
+        fs, ft = ocl.encode_text(sd, cfg, rk.tokenize(src).long()), ocl.encode_text(sd, cfg, rk.tokenize(tgt).long())
+        rcs, rds = ocl.directional_scores(fi, fo, fs, ft)
+    e_img = _feat_err(rk.features(img=img.cuda()), fi)
+    e_txt = _feat_err(rk.features(text=tgt), ft)
+    report.add("oclip/vit_b32", image_rel=e_img, text_rel=e_txt, clip_score_err=float((cs.cpu() - rcs).abs().max()),
+               dclip_score_err=float((ds.cpu() - rds).abs().max()))
+    assert e_img < 8e-3 * FMT and e_txt < 8e-3 * FMT, (e_img, e_txt)
+    assert (cs.cpu() - rcs).abs().max() < 5e-3 * FMT and (ds.cpu() - rds).abs().max() < 2e-2 * FMT
