@@ -21,7 +21,7 @@ import torch
 
 from .. import _ffi, schedule
 from ..engine import kl_f8_vae_desc, ldm_text_unet_desc, sd_v1_unet_desc
-from ..runtime import get_engine, load_or_init_weights
+from ..runtime import get_engine, load_or_init_weights, read_checkpoint
 
 
 class StandInTextEmbedder:
@@ -72,18 +72,19 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
         self.vae = self.engine.create_net(vdesc)
         self.vae_factor = 2 ** (vdesc.n_mult - 1)
         ckpt = self.checkpoint_path(source_model_type)
+        ckpt_sd = read_checkpoint(ckpt)
         self.weights_origin = load_or_init_weights(self.engine, ckpt, {
-            self.unet: "model.diffusion_model.", self.vae: "first_stage_model."})
+            self.unet: "model.diffusion_model.", self.vae: "first_stage_model."}, state_dict=ckpt_sd)
         if cond_stage is None and text_encoder == "clip":
             # `[gan] text_encoder = clip`: FrozenCLIPEmbedder on the engine (768-wide contexts: the SD U-Net)
             from .text_encoders import FrozenCLIPEmbedderHIP
             assert udesc.context_dim == 768, "the CLIP ViT-L/14 text encoder conditions the SD-v1 U-Net"
-            cond_stage = FrozenCLIPEmbedderHIP(self.engine)
+            cond_stage = FrozenCLIPEmbedderHIP(self.engine, state_dict=ckpt_sd)  # cond_stage_model.transformer.*
         elif cond_stage is None and text_encoder == "bert":
             # `[gan] text_encoder = bert`: BERTEmbedder of LDM text2img-large (1280-wide contexts)
             from .text_encoders import BERTEmbedderHIP
             assert udesc.context_dim == 1280, "the BERT / x-transformer encoder conditions the LDM text2img U-Net"
-            cond_stage = BERTEmbedderHIP(self.engine)
+            cond_stage = BERTEmbedderHIP(self.engine, state_dict=ckpt_sd)
         self.cond_stage = cond_stage or StandInTextEmbedder(udesc.context_dim)
         if ranker == "directional_clip":  # `[gan] ranker = directional_clip`: the reference's DirectionalCLIP on the engine
             from .ranker import DirectionalCLIPHIP

@@ -25,15 +25,24 @@ def get_engine(device=None):
     return _ENGINES[key]
 
 
-def load_or_init_weights(engine, ckpt_path, nets_and_prefixes, seed=0):
+def read_checkpoint(ckpt_path):
+    """The reference's checkpoint formats: pl_sd["state_dict"] (txt2img.py:25-42) or a plain dict
+    (ddpm_ddim_wrapper.py:378-379). None when the file does not exist."""
+    if not (ckpt_path and os.path.exists(ckpt_path)):
+        return None
+    sd = torch.load(ckpt_path, map_location="cpu")
+    if isinstance(sd, dict) and "state_dict" in sd:
+        sd = sd["state_dict"]
+    return sd
+
+
+def load_or_init_weights(engine, ckpt_path, nets_and_prefixes, seed=0, state_dict=None):
     """Load a reference checkpoint by its state_dict names (txt2img.py:25-42: pl_sd["state_dict"];
     ddpm_ddim_wrapper.py:378-379: plain dict). There are no checkpoints in this tree (ckpts/ is empty,
     SURVEY.md §0): unless CYCLEDIFF_SYNTHETIC_WEIGHTS=0, missing files fall back to seeded synthetic
     weights (identical on every rank) so configs still run end to end."""
-    if ckpt_path and os.path.exists(ckpt_path):
-        sd = torch.load(ckpt_path, map_location="cpu")
-        if isinstance(sd, dict) and "state_dict" in sd:
-            sd = sd["state_dict"]
+    sd = state_dict if state_dict is not None else read_checkpoint(ckpt_path)
+    if sd is not None:
         for net, prefix in nets_and_prefixes.items():
             n, first = engine.load_state_dict(net, sd, prefix=prefix, strict=True)
             if n:

@@ -182,3 +182,41 @@ def test_pixel_wrapper_ddim_type_vs_oracle(report):
     zerr, p_ref, p_img = _pixel_case("ddim", 0.1, 20, 14)
     report.add("wrapper/pixel_ddim", z_rel=zerr, psnr_vs_oracle=p_ref, psnr_vs_input=p_img)
     assert zerr < 2e-2 * FMT and p_ref > 9.0, (zerr, p_ref)
+
+
+# ------------------------------------------------------------------ checkpoint import by the reference's names
+def test_wrapper_loads_a_reference_style_checkpoint(tmp_path):
+    """pl checkpoint layout of Stable Diffusion (txt2img.py:25-42): {"state_dict": {"model.diffusion_model.*",
+    "first_stage_model.*", "cond_stage_model.*", plus tensors the engine does not consume}}."""
+    from cycle_diffusion_amd import make_desc
+    probe = _make(fold=True)[0]
+    usd = nets.synth_state_dict(probe.engine.net_params(probe.unet), 91)
+    vsd = nets.synth_state_dict(probe.engine.net_params(probe.vae), 92)
+    sd = {"model.diffusion_model." + k: v for k, v in usd.items()}
+    sd.update({"first_stage_model." + k: v for k, v in vsd.items()})
+    sd["model_ema.decay"] = torch.tensor(0.999)           # present in real checkpoints, not consumed
+    sd["first_stage_model.loss.logvar"] = torch.zeros(1)
+    path = tmp_path / "tiny.ckpt"
+    torch.save({"state_dict": sd, "global_step": 1}, str(path))
+
+    class FromCkpt(TinyTextWrapper):
+        @staticmethod
+        def checkpoint_path(source_model_type):
+            return str(path)
+
+    w = FromCkpt(source_model_type="tiny.ckpt", custom_steps=STEPS, eta=0.1, white_box_steps=WB, skip_steps=[0],
+                 encoder_unconditional_guidance_scales=[1.0], decoder_unconditional_guidance_scales=[1.0], n_trials=1,
+                 cond_stage=FixedEmbedder())
+    assert w.weights_origin == str(path)
+    x, t, ctx = gu.tiny_sd_inputs()
+    y = w.engine.unet_forward(w.unet, x.cuda(), t.float().cuda(), ctx.cuda())
+    assert w.engine.load_state_dict(probe.unet, usd)[0] == 0
+    y2 = probe.engine.unet_forward(probe.unet, x.cuda(), t.float().cuda(), ctx.cuda())
+    assert torch.equal(y, y2)
+    # a checkpoint that lacks tensors the engine needs is an error, not a silent partial load
+    del sd["model.diffusion_model.out.2.weight"]
+    torch.save({"state_dict": sd}, str(path))
+    with pytest.raises(KeyError):
+        FromCkpt(source_model_type="tiny.ckpt", custom_steps=STEPS, eta=0.1, white_box_steps=WB, skip_steps=[0],
+                 encoder_unconditional_guidance_scales=[1.0], decoder_unconditional_guidance_scales=[1.0], n_trials=1,
+                 cond_stage=FixedEmbedder())
