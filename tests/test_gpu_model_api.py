@@ -1,0 +1,34 @@
+"""The model API the reference's main.py drives (model/unsupervised_translation.py:9-62,
+model/text_unsupervised_translation.py:24-40): config file -> get_model(args.model.name)(args) -> forward(**batch)
+returns ((original_image, img), zeros[B], {}). BASELINE config 1 (toy DDPM, two wrappers from one [gan] section) runs
+unchanged from config/experiments/toy_ddpm_c1.cfg."""
+import os
+import warnings
+
+import pytest
+import torch
+
+from cycle_diffusion_amd.utils.config_utils import get_config
+from cycle_diffusion_amd.utils.program_utils import get_model
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_unsupervised_translation_from_the_c1_config():
+    args = get_config("experiments/toy_ddpm_c1.cfg", config_root=os.path.join(ROOT, "config"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = get_model(args.model.name)(args).eval()
+    assert model.source_gan_wrapper.resolution == model.target_gan_wrapper.resolution == 32
+    assert model.source_gan_wrapper.latent_dim == 32 * 32 * 3 * 50
+    img = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(1)).cuda()
+    sid = torch.arange(2).cuda()
+    with torch.no_grad():
+        (orig, out), loss, extra = model(sample_id=sid, original_image=img)
+    assert orig is img and out.shape == img.shape and torch.isfinite(out).all()
+    assert loss.shape == (2,) and float(loss.abs().sum()) == 0.0 and extra == {}
+    assert next(model.parameters()).is_cuda  # the trainer reads the device from the parameters
+    # source and target are the same toy network (same model type -> same seeded weights): translating is a cycle
+    mse = ((out.clamp(0, 1) - img) ** 2).mean().item()
+    assert mse < 0.2, mse
