@@ -32,6 +32,12 @@ class TinyTextWrapper(_LatentStochasticTextWrapper):
         return None
 
 
+class TinyLdmTextWrapper(TinyTextWrapper):
+    """the LatentDiffStochasticText twin: posterior MEAN instead of a sample
+    (model/lib/latentdiff/ldm/models/diffusion/ddpm.py:535-538)"""
+    SAMPLE_POSTERIOR = False
+
+
 class FixedEmbedder:
     def __init__(self):
         self.table = {}
@@ -46,7 +52,7 @@ class FixedEmbedder:
         return torch.stack(out, 0)
 
 
-def _make(fold, **kw):
+def _make(fold, cls=None, **kw):
     emb = FixedEmbedder()
     args = dict(source_model_type="none", custom_steps=STEPS, eta=0.1, white_box_steps=WB, skip_steps=[0, 4],
                 encoder_unconditional_guidance_scales=[1.0], decoder_unconditional_guidance_scales=[1.0, 3.0],
@@ -56,19 +62,19 @@ def _make(fold, **kw):
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        w = TinyTextWrapper(**args)
+        w = (cls or TinyTextWrapper)(**args)
     usd = nets.synth_state_dict(w.engine.net_params(w.unet), 31)
     vsd = nets.synth_state_dict(w.engine.net_params(w.vae), 32)
     assert w.engine.load_state_dict(w.unet, usd)[0] == 0 and w.engine.load_state_dict(w.vae, vsd)[0] == 0
     return w, emb, usd, vsd
 
 
-def _oracle(emb, usd, vsd, image, src, tgt, seed):
+def _oracle(emb, usd, vsd, image, src, tgt, seed, sample=True):
     torch.manual_seed(seed)
     B = image.shape[0]
     with torch.no_grad():
         mom = nets.vae_encode_moments(vsd, gu.TINY_VAE_CFG, (image - 0.5) * 2.0)
-        x0 = nets.posterior_sample(mom, torch.randn(B, 4, 16, 16)) * 0.18215
+        x0 = (nets.posterior_sample(mom, torch.randn(B, 4, 16, 16)) if sample else mom[:, :4]) * 0.18215
         unet = lambda x, t, c: nets.openai_unet(usd, gu.TINY_SD_CFG, x, t, c)
         c_src, c_tgt, uc = emb(src), emb(tgt), emb(B * [""])
         zs, imgs = [], []
@@ -220,3 +226,17 @@ def test_wrapper_loads_a_reference_style_checkpoint(tmp_path):
         FromCkpt(source_model_type="tiny.ckpt", custom_steps=STEPS, eta=0.1, white_box_steps=WB, skip_steps=[0],
                  encoder_unconditional_guidance_scales=[1.0], decoder_unconditional_guidance_scales=[1.0], n_trials=1,
                  cond_stage=FixedEmbedder())
+
+
+def test_ldm_text_wrapper_uses_the_posterior_mean(report):
+    image = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(6))
+    src, tgt = ["a", "b"], ["c", "d"]
+    w, emb, usd, vsd = _make(fold=True, cls=TinyLdmTextWrapper)
+    torch.manual_seed(78)
+    with torch.no_grad():
+        z_ens = w.encode(image.cuda(), src)
+        imgs = w.generate(z_ens, tgt)
+    _, imgs_ref = _oracle(emb, usd, vsd, image, src, tgt, 78, sample=False)
+    ps = min(gu.psnr(a.cpu(), b) for a, b in zip(imgs, imgs_ref))
+    report.add("wrapper/ldm_text_api", min_psnr_db=ps)
+    assert len(imgs) == 8 and ps > PSNR_FLOOR, ps
