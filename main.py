@@ -1,0 +1,93 @@
+"""Evaluation driver: config + triplet JSON -> translated images + metrics, on the HIP engine.
+
+A compact stand-in for the reference's `main.py --do_eval` (HF Trainer harness, main.py:57-160,
+trainer/trainer.py:793-900): same experiment configs (`--cfg experiments/*.cfg`), same model API, same per-rank
+sharding (contiguous slices, ShardSampler) and the same per-image metrics (evaluation/translate_text.py: PSNR, SSIM,
+L2 against the input; CLIP / directional CLIP when the config selects `ranker = directional_clip`).
+
+  python main.py --cfg experiments/toy_ddpm_c1.cfg --data triplets.json --output_dir out [--per_device_eval_batch_size 4]
+  python -m torch.distributed.run --nproc-per-node 8 main.py ...        # one process per GPU
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfg", required=True)
+    ap.add_argument("--data", required=True, help="JSON list of {img_path[, encode_text, decode_text]}")
+    ap.add_argument("--output_dir", default="output")
+    ap.add_argument("--per_device_eval_batch_size", type=int, default=4)
+    ap.add_argument("--range", type=int, nargs=2, default=None, metavar=("START", "END"))
+    ap.add_argument("--seed", type=int, default=42)
+    a = ap.parse_args(argv)
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import cycle_diffusion_amd  # noqa: F401
+    from cycle_diffusion_amd.data.triplets import TripletDataset, collate
+    from cycle_diffusion_amd.parallel import shard_range
+    from cycle_diffusion_amd.utils import metrics
+    from cycle_diffusion_amd.utils.config_utils import get_config
+    from cycle_diffusion_amd.utils.program_utils import get_model
+
+    args = get_config(a.cfg, config_root=os.path.join(ROOT, "config"))
+    torch.manual_seed(a.seed)  # same weights / streams on every rank (main.py:66 set_seed)
+    model = get_model(args.model.name)(args).eval()
+    wrapper = getattr(model, "gan_wrapper", None) or model.source_gan_wrapper
+    start, end = a.range if a.range else (0, None)
+    ds = TripletDataset(a.data, wrapper.resolution, start, end)
+    lo, hi = shard_range(len(ds), world, rank)
+    os.makedirs(a.output_dir, exist_ok=True)
+    dev = torch.device("cuda", local)
+    rows = []
+    for b0 in range(lo, hi, a.per_device_eval_batch_size):
+        batch = collate([ds[i] for i in range(b0, min(hi, b0 + a.per_device_eval_batch_size))])
+        kw = {"sample_id": batch["sample_id"].to(dev), "original_image": batch["original_image"].to(dev)}
+        if "encode_text" in batch:
+            kw.update(encode_text=batch["encode_text"], decode_text=batch["decode_text"])
+        with torch.no_grad():
+            (orig, img), _loss, _ = model(**kw)
+        for j in range(img.shape[0]):
+            o, g = orig[j].clamp(0, 1).cpu(), img[j].clamp(0, 1).cpu()
+            sid = int(batch["sample_id"][j])
+            row = {"sample_id": sid, "psnr": float(metrics.calculate_psnr(g, o)),
+                   "ssim": float(metrics.calculate_ssim(g.permute(1, 2, 0) * 255, o.permute(1, 2, 0) * 255)),
+                   "l2": float(metrics.calculate_l2(g, o))}
+            for k in ("encode_text", "decode_text"):
+                if k in batch:
+                    row[k] = batch[k][j]
+            rows.append(row)
+            from PIL import Image
+            Image.fromarray((g.permute(1, 2, 0).numpy() * 255 + 0.5).astype("uint8")).save(
+                os.path.join(a.output_dir, "%06d.png" % sid))
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rows)
+        rows = [r for part in gathered for r in part]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        rows.sort(key=lambda r: r["sample_id"])
+        summary = {k: sum(r[k] for r in rows) / max(1, len(rows)) for k in ("psnr", "ssim", "l2")}
+        with open(os.path.join(a.output_dir, "metrics.json"), "w") as fh:
+            json.dump({"summary": summary, "samples": rows}, fh, indent=1)
+        print(json.dumps({"n": len(rows), **summary}))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -32,3 +32,28 @@ def test_unsupervised_translation_from_the_c1_config():
     # source and target are the same toy network (same model type -> same seeded weights): translating is a cycle
     mse = ((out.clamp(0, 1) - img) ** 2).mean().item()
     assert mse < 0.2, mse
+
+
+def test_main_driver_on_the_c1_config(tmp_path):
+    """main.py: config + triplet JSON -> images + metrics.json (unpaired entries carry only img_path)."""
+    import json
+    import sys
+    import numpy as np
+    from PIL import Image
+    rng = np.random.RandomState(0)
+    meta = []
+    for i in range(3):
+        Image.fromarray(rng.randint(0, 255, (40, 32, 3), dtype=np.uint8)).save(tmp_path / ("im%d.png" % i))
+        meta.append({"img_path": "im%d.png" % i})
+    (tmp_path / "data.json").write_text(json.dumps(meta))
+    sys.path.insert(0, ROOT)
+    import main as driver
+    out = tmp_path / "out"
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert driver.main(["--cfg", "experiments/toy_ddpm_c1.cfg", "--data", str(tmp_path / "data.json"),
+                            "--output_dir", str(out), "--per_device_eval_batch_size", "2"]) == 0
+    res = json.loads((out / "metrics.json").read_text())
+    assert len(res["samples"]) == 3 and [r["sample_id"] for r in res["samples"]] == [0, 1, 2]
+    assert all(np.isfinite(r["psnr"]) and 0 <= r["ssim"] <= 1 for r in res["samples"])
+    assert sorted(p.name for p in out.glob("*.png")) == ["000000.png", "000001.png", "000002.png"]
