@@ -105,9 +105,10 @@ def main():
                     help="initialise the RCCL process group even at world size 1 (exercises the gather path on a 1-GPU box)")
     a = ap.parse_args()
 
-    torch.set_num_threads(host_cores())  # host-side weight synthesis / oracle: stay inside the CPU quota
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # host-side weight synthesis / oracle: stay inside the CPU quota, shared by the ranks of the node
+    torch.set_num_threads(max(1, host_cores() // max(1, world)))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 or world > 1 or a.force_dist:
         assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
@@ -131,6 +132,7 @@ def main():
     # workgroups per CU): two independent batches in flight on two HIP streams raise whole-GPU
     # throughput ~1.4x. Replica r owns stream r, its own engine (workspace, split-K scratch) and weights.
     n_rep = max(1, a.in_flight)
+    os.environ["CYCLEDIFF_SHARE_SYNTH"] = "1" if n_rep > 1 else "0"  # generate the synthetic weights once per rank
     replicas = []
     for r in range(n_rep):
         st = torch.cuda.Stream(device=dev) if n_rep > 1 else torch.cuda.current_stream(dev)
@@ -139,6 +141,7 @@ def main():
             replicas.append((st, get_model(args.model.name)(args).eval()))
     model = replicas[0][1]
     eng = model.gan_wrapper.engine
+    cda.Engine._SYNTH_CACHE.clear()
 
     # synthetic batch: global batch = B * world, rank r takes its contiguous slice (ShardSampler, trainer.py:288-293)
     B = a.batch

@@ -172,11 +172,22 @@ class Engine:
         check(self.lib.cd_net_missing_params(self.h, net, C.byref(n), buf, 512))
         return n.value, buf.value.decode()
 
-    def random_init(self, net, seed=0, std=0.02):
+    _SYNTH_CACHE = {}  # (seed, names+shapes) -> tensors; lets several engines of one process share the host work
+
+    def random_init(self, net, seed=0, std=0.02, cache=False):
         """Synthetic weights for benchmarks: N(0, fan-in scaled) matrices, unit norms.
         (There are no checkpoints in the tree)"""
+        params = self.net_params(net)
+        key = (seed, tuple((n, tuple(s)) for n, s in params))
+        if cache and key in Engine._SYNTH_CACHE:
+            for (name, _), t in zip(params, Engine._SYNTH_CACHE[key]):
+                self.load_param(net, name, t)
+            n, first = self.missing(net)
+            assert n == 0, first
+            return
+        made = []
         g = torch.Generator().manual_seed(seed)
-        for name, shape in self.net_params(net):
+        for name, shape in params:
             if len(shape) == 1:
                 base = name.rsplit(".", 1)[0]
                 is_norm = name.endswith("weight") and (".norm" in name or "in_layers.0" in name or "out_layers.0" in name
@@ -192,6 +203,10 @@ class Engine:
                 fan_in = int(np.prod(shape[1:]))
                 t = torch.randn(shape, generator=g) * (1.0 / np.sqrt(fan_in))
             self.load_param(net, name, t)
+            if cache:
+                made.append(t)
+        if cache:
+            Engine._SYNTH_CACHE[key] = made
         n, first = self.missing(net)
         assert n == 0, first
 

@@ -51,6 +51,7 @@ def load_or_init_weights(engine, ckpt_path, nets_and_prefixes, seed=0, state_dic
     if os.environ.get("CYCLEDIFF_SYNTHETIC_WEIGHTS", "1") == "0":
         raise FileNotFoundError(ckpt_path)
     warnings.warn("checkpoint %s not found: using seeded synthetic weights" % ckpt_path)
+    share = os.environ.get("CYCLEDIFF_SHARE_SYNTH", "0") == "1"  # bench.py: several replicas, same seeds
     for i, net in enumerate(nets_and_prefixes):
-        engine.random_init(net, seed=seed + i)
+        engine.random_init(net, seed=seed + i, cache=share)
     return "synthetic(seed=%d)" % seed
