@@ -15,7 +15,6 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 import torch
@@ -124,7 +123,7 @@ def main():
     import cycle_diffusion_amd as cda  # noqa: F401  (builds nothing: the .so travels in-tree)
     from cycle_diffusion_amd.utils.config_utils import get_config
     from cycle_diffusion_amd.utils.program_utils import get_model
-    from cycle_diffusion_amd.parallel import gather_outputs, shard_range
+    from cycle_diffusion_amd.parallel import gather_outputs, run_in_flight, shard_range
 
     os.environ["LOCAL_RANK"] = str(local)
     args = get_config("experiments/bench_sd_c2.cfg", config_root=os.path.join(ROOT, "config"))
@@ -153,43 +152,24 @@ def main():
     tgt = ["target prompt %d" % i for i in range(lo, hi)]
     torch.manual_seed(4 + rank)  # per-rank noise streams
 
-    def compute(r, res):
+    def compute(r):
         st, m = replicas[r]
         torch.cuda.set_device(dev)  # the current device is per host thread
         with torch.cuda.stream(st), torch.no_grad():
-            res[r] = m(sample_id=sample_id, original_image=images, encode_text=src, decode_text=tgt)
+            return m(sample_id=sample_id, original_image=images, encode_text=src, decode_text=tgt)
 
     def gather(r, res):
-        (orig, img), loss, _ = res[r]
+        (orig, img), loss, _ = res
         torch.cuda.current_stream(dev).wait_stream(replicas[r][0])
         return gather_outputs((orig, img), loss)  # one all-gather per eval step (trainer.py:833)
 
     def step(r=0):
-        res = {}
-        compute(r, res)
-        return gather(r, res)
+        return gather(r, compute(r))
 
     def run_steps(n):
-        """n steps, up to n_rep of them in flight: one host thread per replica computes, then the main thread
-        does that round's all-gathers in step order (every rank issues its collectives in the same order)."""
-        out = None
-        done = 0
-        while done < n:
-            k = min(n_rep, n - done)
-            res = {}
-            if k == 1:
-                compute(0, res)
-            else:
-                ths = [threading.Thread(target=compute, args=(r, res)) for r in range(k)]
-                for t in ths:
-                    t.start()
-                for t in ths:
-                    t.join()
-            for r in range(k):
-                assert r in res, "replica %d failed" % r
-                out = gather(r, res)
-            done += k
-        return out
+        """n steps, up to n_rep of them in flight: one host thread per replica computes, then the main thread does
+        that round's all-gathers in step order (parallel.run_in_flight)."""
+        return run_in_flight(n, n_rep, compute, gather)
 
     def sync():
         if dist.is_initialized():

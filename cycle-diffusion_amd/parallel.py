@@ -36,3 +36,37 @@ def _gather_nested(t):
     if isinstance(t, (tuple, list)):
         return type(t)(_gather_nested(x) for x in t)
     return _concat(t)
+
+
+def run_in_flight(n_steps, n_replicas, compute, finish):
+    """Run `n_steps` independent steps with up to `n_replicas` of them in flight (bench.py: one engine replica per
+    HIP stream). Each round starts one host thread per replica running `compute(replica) -> result`; when the round's
+    threads have joined, the MAIN thread calls `finish(replica, result)` for the round's steps in step order - that is
+    where collectives go, so every rank issues them in the same order no matter how its threads were scheduled.
+    Returns the last `finish` value. A replica that raises aborts the run with that exception."""
+    import threading
+    out, done = None, 0
+    while done < n_steps:
+        k = min(n_replicas, n_steps - done)
+        res, err = {}, {}
+
+        def work(r):
+            try:
+                res[r] = compute(r)
+            except BaseException as e:  # noqa: BLE001 - re-raised on the main thread
+                err[r] = e
+
+        if k == 1:
+            work(0)
+        else:
+            ths = [threading.Thread(target=work, args=(r,)) for r in range(k)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+        if err:
+            raise err[min(err)]
+        for r in range(k):
+            out = finish(r, res[r])
+        done += k
+    return out

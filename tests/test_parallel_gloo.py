@@ -55,3 +55,56 @@ def test_gather_reproduces_global_order_world2():
         assert p.exitcode == 0
     assert all(ok for _, ok, _, _ in res), res
     assert sorted((lo, hi) for _, _, lo, hi in res) == [(0, 4), (4, 8)]
+
+
+def _worker_in_flight(rank, world, port, q):
+    """bench.py's N>1 schedule on CPU: 3 replicas in flight, 7 steps, jittered compute threads, one all-gather per step
+    issued by the main thread in step order on every rank."""
+    import random
+    import time
+    from cycle_diffusion_amd.parallel import run_in_flight
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = random.Random(100 + rank)
+    counter = {"step": 0}
+    seen = []
+
+    def compute(r):
+        time.sleep(rng.random() * 0.05)  # threads finish in a different order on every rank
+        return torch.full((2, 3), float(rank * 100 + r))
+
+    def finish(r, res):
+        out, _ = gather_outputs((res,), None)
+        seen.append((counter["step"], r, out[0][:, 0].tolist()))
+        counter["step"] += 1
+        return out[0]
+
+    last = run_in_flight(7, 3, compute, finish)
+    ok = len(seen) == 7 and [s for s, _, _ in seen] == list(range(7))
+    ok = ok and [r for _, r, _ in seen] == [0, 1, 2, 0, 1, 2, 0]  # rounds of 3, 3, 1
+    ok = ok and all(v == [0.0 + r, 0.0 + r, 100.0 + r, 100.0 + r] for _, r, v in seen)  # rank-major, same replica
+    ok = ok and last.shape == (4, 3)
+    try:
+        run_in_flight(2, 2, lambda r: (_ for _ in ()).throw(ValueError("boom")) if r == 1 else 0, lambda r, x: x)
+        ok = False
+    except ValueError:
+        pass
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_in_flight_rounds_keep_collectives_in_step_order_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_in_flight, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
