@@ -126,6 +126,7 @@ def main():
     from cycle_diffusion_amd.parallel import gather_outputs, run_in_flight, shard_range
 
     os.environ["LOCAL_RANK"] = str(local)
+    os.environ["CYCLEDIFF_SYNTHETIC_WEIGHTS"] = "1"  # no checkpoints in this tree: seeded synthetic weights (opt-in)
     args = get_config("experiments/bench_sd_c2.cfg", config_root=os.path.join(ROOT, "config"))
     # A single stream of these kernels leaves the GPU under-occupied (most launches are wait-bound at 1-3
     # workgroups per CU): two independent batches in flight on two HIP streams raise whole-GPU

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcyclediff.so")
 CD_NET_UNET_OPENAI, CD_NET_UNET_HO, CD_NET_VAE_KL, CD_NET_CLIP_TEXT, CD_NET_BERT_XTR = 1, 2, 3, 4, 5
 CD_NET_OCLIP_TEXT, CD_NET_OCLIP_VISION = 6, 7
 CD_SCHED_DDIM, CD_SCHED_DDPM = 0, 1
+CD_PREC_16, CD_PREC_F32 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
 
 
@@ -28,7 +29,7 @@ class NetDesc(C.Structure):
         ("use_spatial_transformer", C.c_int), ("context_dim", C.c_int), ("transformer_depth", C.c_int),
         ("use_scale_shift_norm", C.c_int), ("resblock_updown", C.c_int), ("conv_resample", C.c_int),
         ("z_channels", C.c_int), ("embed_dim", C.c_int), ("double_z", C.c_int),
-        ("reserved", C.c_int * 8),
+        ("precision", C.c_int), ("reserved", C.c_int * 7),
     ]
 
 

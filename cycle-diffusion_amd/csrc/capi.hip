@@ -27,6 +27,18 @@ struct cd_engine {
   }
 };
 
+// Restores the engine's bump arena on every exit path of an entry point, including a CD_CHECK / HIP_CHECK that throws
+// into CD_API_END (an un-restored arena would stay elevated - after an out-of-workspace error nearly full - and make
+// later, smaller calls fail until the engine is destroyed).
+struct ArenaScope {
+  Arena& a;
+  size_t m;
+  explicit ArenaScope(Arena& arena) : a(arena), m(arena.mark()) {}
+  ~ArenaScope() { a.release(m); }
+  ArenaScope(const ArenaScope&) = delete;
+  ArenaScope& operator=(const ArenaScope&) = delete;
+};
+
 static thread_local std::string g_err;
 
 // Engines are independent (own stream, arena, workspaces): several may run concurrently from different host
@@ -250,6 +262,8 @@ struct SamplerState {
   UNet* u = nullptr;
   int B = 0, Bn = 0, C = 0, HW = 0, cpad = 0, out_ld = 0;
   bool cfg = false;
+  bool f32 = false;  // CD_PREC_F32 network: its NHWC input is fp32 and is rebuilt from xt before every forward
+  bf16_t* xin16() const { return f32 ? nullptr : xin; }
   float g = 1.f;
   float* xt = nullptr;
   bf16_t* xin = nullptr;
@@ -276,9 +290,12 @@ SamplerState setup_sampler(cd_engine* h, int net, const float* ctx_c, const floa
     CD_CHECK(s.u->desc.context_dim <= 0 || !s.u->desc.use_spatial_transformer,
              "network expects a cross-attention context");
   }
+  s.f32 = s.u->f32;
+  CD_CHECK(!(s.f32 && s.cfg), "CD_PREC_F32 networks are unconditional (no classifier-free guidance batch)");
+  const size_t esz = s.f32 ? 4 : 2;
   s.xt = (float*)h->arena.alloc((size_t)B * s.C * s.HW * 4);
-  s.xin = (bf16_t*)h->arena.alloc((size_t)s.Bn * s.HW * s.cpad * 2);
-  HIP_CHECK(hipMemsetAsync(s.xin, 0, (size_t)s.Bn * s.HW * s.cpad * 2, h->st));
+  s.xin = (bf16_t*)h->arena.alloc((size_t)s.Bn * s.HW * s.cpad * esz);
+  HIP_CHECK(hipMemsetAsync(s.xin, 0, (size_t)s.Bn * s.HW * s.cpad * esz, h->st));
   s.eh = (float*)h->arena.alloc((size_t)s.Bn * s.HW * s.out_ld * 4);
   s.ehv.p = s.eh; s.ehv.sb = (int64_t)s.HW * s.out_ld; s.ehv.sc = 1; s.ehv.sp = s.out_ld;
   s.ehv.cfg = s.cfg ? 1 : 0; s.ehv.g = guidance;
@@ -287,6 +304,7 @@ SamplerState setup_sampler(cd_engine* h, int net, const float* ctx_c, const floa
 
 void run_unet(cd_engine* h, SamplerState& s, int step) {
   Ctx c = h->ctx();
+  if (s.f32) launch_nchw_to_nhwc_f32(h->st, s.xt, (float*)s.xin, s.B, s.C, s.HW, s.cpad, 1.f, 0.f);
   UNetIO io;
   io.xin = s.xin; io.B = s.Bn; io.tab = s.tab; io.step = step; io.t_shared = true;
   io.out = s.eh; io.out_ld = s.out_ld;
@@ -303,7 +321,7 @@ int cd_unet_forward(cd_handle h, int net, const float* x, const float* t, const 
   enter_engine(h);
   UNet* u = get_unet(h, net);
   CD_CHECK(x && t && eps_out && B > 0, "bad argument");
-  const size_t mk = h->arena.mark();
+  ArenaScope arena_scope(h->arena);
   Ctx c = h->ctx();
   const int C = u->desc.in_channels, HW = u->image_size * u->image_size, Co = u->out_channels;
   if (ctx) {
@@ -312,13 +330,13 @@ int cd_unet_forward(cd_handle h, int net, const float* x, const float* t, const 
     bf16_t* cx = make_ctx(h, ctx, nullptr, B, ctx_len, Dc);
     u->set_context(c, cx, B, ctx_len);
   }
-  bf16_t* xin = (bf16_t*)h->arena.alloc((size_t)B * HW * u->in_cpad * 2);
-  launch_nchw_to_nhwc(h->st, x, xin, B, C, HW, u->in_cpad, 1.f, 0.f, 0);
+  bf16_t* xin = (bf16_t*)h->arena.alloc((size_t)B * HW * u->in_cpad * (u->f32 ? 4 : 2));
+  if (u->f32) launch_nchw_to_nhwc_f32(h->st, x, (float*)xin, B, C, HW, u->in_cpad, 1.f, 0.f);
+  else launch_nchw_to_nhwc(h->st, x, xin, B, C, HW, u->in_cpad, 1.f, 0.f, 0);
   float* eh = (float*)h->arena.alloc((size_t)B * HW * Co * 4);
   UNetIO io; io.xin = xin; io.B = B; io.t_explicit = t; io.t_shared = false; io.out = eh; io.out_ld = Co;
   u->forward(c, io);
   launch_nhwc_to_nchw(h->st, eh, 1, Co, eps_out, B, Co, HW, 1.f, 0.f);
-  h->arena.release(mk);
   CD_API_END
 }
 
@@ -329,6 +347,8 @@ int cd_text_encode(cd_handle h, int net, const int32_t* tokens, int B, int L, fl
                (h->nets[net]->kind() == CD_NET_CLIP_TEXT || h->nets[net]->kind() == CD_NET_BERT_XTR),
            "net %d is not a text encoder", net);
   CD_CHECK(tokens && out && B > 0 && L > 0, "bad argument");
+  CD_CHECK(h, "null handle");
+  ArenaScope arena_scope(h->arena);
   Ctx c = h->ctx();
   static_cast<TextEncoder*>(h->nets[net].get())->encode(c, (const int*)tokens, B, L, out);
   CD_API_END
@@ -343,6 +363,8 @@ int cd_clip_text_features(cd_handle h, int net, const int32_t* tokens, int B, in
   CD_API_BEGIN
   enter_engine(h);
   CD_CHECK(tokens && out && B > 0 && L > 0, "bad argument");
+  CD_CHECK(h, "null handle");
+  ArenaScope arena_scope(h->arena);
   Ctx c = h->ctx();
   get_tower(h, net, CD_NET_OCLIP_TEXT)->text_features(c, (const int*)tokens, B, L, out);
   CD_API_END
@@ -352,6 +374,8 @@ int cd_clip_image_features(cd_handle h, int net, const float* img, int B, float*
   CD_API_BEGIN
   enter_engine(h);
   CD_CHECK(img && out && B > 0, "bad argument");
+  CD_CHECK(h, "null handle");
+  ArenaScope arena_scope(h->arena);
   Ctx c = h->ctx();
   get_tower(h, net, CD_NET_OCLIP_VISION)->image_features(c, img, B, out);
   CD_API_END
@@ -363,7 +387,7 @@ int cd_vae_encode(cd_handle h, int net, const float* img, const float* noise, ui
   enter_engine(h);
   VAE* v = get_vae(h, net);
   CD_CHECK(img && z0 && B > 0 && R % v->factor == 0, "bad argument");
-  const size_t mk = h->arena.mark();
+  ArenaScope arena_scope(h->arena);
   Ctx c = h->ctx();
   const int cin = v->desc.in_channels, cp = round_up(cin, 32), hl = R / v->factor;
   bf16_t* xin = (bf16_t*)h->arena.alloc((size_t)B * R * R * cp * 2);
@@ -372,7 +396,6 @@ int cd_vae_encode(cd_handle h, int net, const float* img, const float* noise, ui
   float* mom = (float*)h->arena.alloc((size_t)B * hl * hl * mch * 4);
   v->encode_moments(c, xin, B, R, mom);
   launch_posterior_sample(h->st, mom, mch, noise, seed, z0, B, v->desc.embed_dim, hl * hl, scale, sample ? 0 : 1);
-  h->arena.release(mk);
   CD_API_END
 }
 
@@ -382,7 +405,7 @@ int cd_vae_decode(cd_handle h, int net, const float* z0, int B, int hlat, float 
   enter_engine(h);
   VAE* v = get_vae(h, net);
   CD_CHECK(z0 && img && B > 0 && hlat > 0, "bad argument");
-  const size_t mk = h->arena.mark();
+  ArenaScope arena_scope(h->arena);
   Ctx c = h->ctx();
   const int zc = v->desc.embed_dim, cp = round_up(zc, 32), R = hlat * v->factor, co = v->desc.out_channels;
   bf16_t* zin = (bf16_t*)h->arena.alloc((size_t)B * hlat * hlat * cp * 2);
@@ -390,7 +413,6 @@ int cd_vae_decode(cd_handle h, int net, const float* z0, int B, int hlat, float 
   float* o = (float*)h->arena.alloc((size_t)B * R * R * co * 4);
   v->decode(c, zin, B, hlat, o);
   launch_nhwc_to_nchw(h->st, o, 1, co, img, B, co, R * R, out_mul, out_add);
-  h->arena.release(mk);
   CD_API_END
 }
 
@@ -401,12 +423,12 @@ int cd_dpm_encode(cd_handle h, int net, int sched_kind, const float* x0, const f
   CD_API_BEGIN
   enter_engine(h);
   CD_CHECK(h && x0 && coef_host && z_out && B > 0 && K > 0, "bad argument");
-  const size_t mk = h->arena.mark();
+  ArenaScope arena_scope(h->arena);
   SamplerState s = setup_sampler(h, net, ctx_c, ctx_uc, ctx_len, guidance, B);
   s.tab = upload_coef(h, coef_host, K + 1);
   const int64_t chw = (int64_t)s.C * s.HW, n = (int64_t)B * chw;
   const int64_t zbs = (int64_t)(K + 1) * chw;
-  launch_init_xt(h->st, x0, noise, seed, 0u, s.xt, z_out, zbs, B, s.C, s.HW, s.tab, K, s.xin, s.cpad,
+  launch_init_xt(h->st, x0, noise, seed, 0u, s.xt, z_out, zbs, B, s.C, s.HW, s.tab, K, s.xin16(), s.cpad,
                  s.cfg ? 1 : 0);
   for (int i = 0; i < K; ++i) {
     const int k = K - 1 - i;
@@ -414,9 +436,8 @@ int cd_dpm_encode(cd_handle h, int net, int sched_kind, const float* x0, const f
     const int is_last = (last_uses_x0 && k == 0) ? 1 : 0;
     const float* nz = (noise && !is_last) ? noise + (int64_t)(1 + i) * n : nullptr;
     launch_encode_step(h->st, sched_kind, x0, s.xt, s.ehv, nz, seed, (uint32_t)(1 + i), z_out + (1 + i) * chw,
-                       zbs, B, s.C, s.HW, s.tab, nullptr, k, is_last, s.xin, s.cpad, s.cfg ? 1 : 0);
+                       zbs, B, s.C, s.HW, s.tab, nullptr, k, is_last, s.xin16(), s.cpad, s.cfg ? 1 : 0);
   }
-  h->arena.release(mk);
   CD_API_END
 }
 
@@ -426,24 +447,23 @@ int cd_ddim_decode(cd_handle h, int net, int sched_kind, const float* z, int z_s
   CD_API_BEGIN
   enter_engine(h);
   CD_CHECK(h && z && coef_host && x_out && B > 0 && K > 0 && n_eps <= z_slots - 1, "bad argument");
-  const size_t mk = h->arena.mark();
+  ArenaScope arena_scope(h->arena);
   SamplerState s = setup_sampler(h, net, ctx_c, ctx_uc, ctx_len, guidance, B);
   s.tab = upload_coef(h, coef_host, K);
   const int64_t chw = (int64_t)s.C * s.HW, n = (int64_t)B * chw;
   const int64_t zbs = (int64_t)z_slots * chw;
   // x = z[:, 0]  (sd_wrapper:153; ddpm_ddim_wrapper.py:404)
   HIP_CHECK(hipMemcpy2DAsync(s.xt, chw * 4, z, zbs * 4, chw * 4, B, hipMemcpyDeviceToDevice, h->st));
-  launch_nchw_to_nhwc(h->st, s.xt, s.xin, B, s.C, s.HW, s.cpad, 1.f, 0.f, s.cfg ? 1 : 0);
+  if (!s.f32) launch_nchw_to_nhwc(h->st, s.xt, s.xin, B, s.C, s.HW, s.cpad, 1.f, 0.f, s.cfg ? 1 : 0);
   for (int i = 0; i < K; ++i) {
     const int k = K - 1 - i;
     run_unet(h, s, k);
     const float* eps = (i < n_eps) ? z + (int64_t)(1 + i) * chw : nullptr;
     const float* nz = (!eps && noise_tail) ? noise_tail + (int64_t)(i - n_eps) * n : nullptr;
     launch_decode_step(h->st, sched_kind, s.xt, s.ehv, eps, zbs, nz, seed, (uint32_t)(0x1000 + i), B, s.C,
-                       s.HW, s.tab, nullptr, k, s.xin, s.cpad, s.cfg ? 1 : 0, nullptr);
+                       s.HW, s.tab, nullptr, k, s.xin16(), s.cpad, s.cfg ? 1 : 0, nullptr);
   }
   HIP_CHECK(hipMemcpyAsync(x_out, s.xt, (size_t)n * 4, hipMemcpyDeviceToDevice, h->st));
-  h->arena.release(mk);
   CD_API_END
 }
 
@@ -452,20 +472,19 @@ int cd_pix_refine(cd_handle h, int net, int sched_kind, float* x, int B, int R, 
   CD_API_BEGIN
   enter_engine(h);
   CD_CHECK(h && x && coef_host && B > 0 && R > 0, "bad argument");
-  const size_t mk = h->arena.mark();
+  ArenaScope arena_scope(h->arena);
   SamplerState s = setup_sampler(h, net, nullptr, nullptr, 0, 1.f, B);
   s.tab = upload_coef(h, coef_host, R + 1);
   const int64_t n = (int64_t)B * s.C * s.HW;
-  launch_init_xt(h->st, x, noise, seed, 0x2000u, s.xt, nullptr, 0, B, s.C, s.HW, s.tab, R, s.xin, s.cpad, 0);
+  launch_init_xt(h->st, x, noise, seed, 0x2000u, s.xt, nullptr, 0, B, s.C, s.HW, s.tab, R, s.xin16(), s.cpad, 0);
   for (int i = 0; i < R; ++i) {
     const int k = R - 1 - i;
     run_unet(h, s, k);
     const float* nz = noise ? noise + (int64_t)(1 + i) * n : nullptr;
     launch_decode_step(h->st, sched_kind, s.xt, s.ehv, nullptr, 0, nz, seed, (uint32_t)(0x2001 + i), B, s.C,
-                       s.HW, s.tab, nullptr, k, s.xin, s.cpad, 0, nullptr);
+                       s.HW, s.tab, nullptr, k, s.xin16(), s.cpad, 0, nullptr);
   }
   HIP_CHECK(hipMemcpyAsync(x, s.xt, (size_t)n * 4, hipMemcpyDeviceToDevice, h->st));
-  h->arena.release(mk);
   CD_API_END
 }
 
@@ -495,7 +514,7 @@ int cd_op_conv2d(cd_handle h, const float* x0, int C0, const float* x1, int C1, 
   CD_API_BEGIN
   enter_engine(h);
   CD_CHECK(h && x0 && packed_w && y, "bad argument");
-  const size_t mk = h->arena.mark();
+  ArenaScope arena_scope(h->arena);
   Ctx c = h->ctx();
   ConvW w = *(const ConvW*)packed_w;
   CD_CHECK(w.N == N && w.KH == KH && w.KW == KW, "packed weight does not match the call");
@@ -523,7 +542,6 @@ int cd_op_conv2d(cd_handle h, const float* x0, int C0, const float* x1, int C1, 
   }
   Act out = conv_fwd(c, w, a0, x1 ? &a1 : nullptr, o);
   launch_nhwc_to_nchw(h->st, out.p, 1, out.ld, y, B, Nout, Ho * Wo, 1.f, 0.f);
-  h->arena.release(mk);
   CD_API_END
 }
 
@@ -532,14 +550,13 @@ int cd_op_groupnorm(cd_handle h, const float* x, int B, int C, int H, int W, int
   CD_API_BEGIN
   enter_engine(h);
   CD_CHECK(h && x && y && G == 32, "bad argument (G must be 32)");
-  const size_t mk = h->arena.mark();
+  ArenaScope arena_scope(h->arena);
   Ctx c = h->ctx();
   Act a = alloc_act(c, B, H, W, C);
   launch_nchw_to_nhwc(h->st, x, a.p, B, C, H * W, C, 1.f, 0.f, 0);
   GNW w; w.g = const_cast<float*>(gamma); w.b = const_cast<float*>(beta); w.C = C; w.eps = eps;
   Act o = groupnorm_fwd(c, w, a, nullptr, silu != 0, film, film ? 2 * C : 0);
   launch_nhwc_to_nchw(h->st, o.p, 0, o.ld, y, B, C, H * W, 1.f, 0.f);
-  h->arena.release(mk);
   CD_API_END
 }
 
@@ -548,13 +565,12 @@ int cd_op_layernorm(cd_handle h, const float* x, int rows, int C, const float* g
   CD_API_BEGIN
   enter_engine(h);
   CD_CHECK(h && x && y, "bad argument");
-  const size_t mk = h->arena.mark();
+  ArenaScope arena_scope(h->arena);
   bf16_t* a = (bf16_t*)h->arena.alloc((size_t)rows * C * 2);
   bf16_t* o = (bf16_t*)h->arena.alloc((size_t)rows * C * 2);
   launch_nchw_to_nhwc(h->st, x, a, rows, C, 1, C, 1.f, 0.f, 0);
   launch_layernorm(h->st, a, C, o, C, rows, C, gamma, beta, eps);
   launch_nhwc_to_nchw(h->st, o, 0, C, y, rows, C, 1, 1.f, 0.f);
-  h->arena.release(mk);
   CD_API_END
 }
 
@@ -564,7 +580,7 @@ int cd_op_attention(cd_handle h, const float* q, const float* k, const float* v,
   enter_engine(h);
   CD_CHECK(h && q && k && v && o, "bad argument");
   (void)use_transpose_kernel;
-  const size_t mk = h->arena.mark();
+  ArenaScope arena_scope(h->arena);
   const int C = H * D, Tpad = round_up(Tk, 64);
   bf16_t* qb = (bf16_t*)h->arena.alloc((size_t)B * Tq * C * 2);
   bf16_t* kb = (bf16_t*)h->arena.alloc((size_t)B * Tk * C * 2);
@@ -581,7 +597,6 @@ int cd_op_attention(cd_handle h, const float* q, const float* k, const float* v,
   p.vt_dpad = D; p.vt_tpad = Tpad; p.scale = scale;
   launch_attention(h->st, p);
   launch_nhwc_to_nchw(h->st, ob, 0, C, o, B * Tq, C, 1, 1.f, 0.f);
-  h->arena.release(mk);
   CD_API_END
 }
 
@@ -589,11 +604,10 @@ int cd_op_softmax_rows(cd_handle h, const float* s, int64_t rows, int cols, floa
   CD_API_BEGIN
   enter_engine(h);
   CD_CHECK(h && s && p, "bad argument");
-  const size_t mk = h->arena.mark();
+  ArenaScope arena_scope(h->arena);
   bf16_t* pb = (bf16_t*)h->arena.alloc((size_t)rows * cols * 2);
   launch_softmax_rows(h->st, s, cols, pb, cols, rows, cols);
   launch_nhwc_to_nchw(h->st, pb, 0, cols, p, (int)rows, cols, 1, 1.f, 0.f);
-  h->arena.release(mk);
   CD_API_END
 }
 
@@ -611,7 +625,7 @@ int cd_op_sched_step(cd_handle h, int mode, int sched_kind, const cd_step_coef* 
   CD_API_BEGIN
   enter_engine(h);
   CD_CHECK(h && coef_host && xt, "bad argument");
-  const size_t mk = h->arena.mark();
+  ArenaScope arena_scope(h->arena);
   StepCoef* tab = upload_coef(h, coef_host, 1);
   const int64_t chw = (int64_t)C * HW;
   EpsHat eh; eh.p = eps_hat; eh.sb = chw; eh.sc = HW; eh.sp = 1; eh.cfg = cfg; eh.g = guidance;  // NCHW view
@@ -625,7 +639,6 @@ int cd_op_sched_step(cd_handle h, int mode, int sched_kind, const cd_step_coef* 
                        0, 0, nullptr);
   }
   HIP_CHECK(hipStreamSynchronize(h->st));
-  h->arena.release(mk);
   CD_API_END
 }
 
@@ -685,7 +698,7 @@ extern "C" int cd_op_bench_conv(cd_handle h, int B, int H, int W, int C0, int C1
   CD_API_BEGIN
   enter_engine(h);
   CD_CHECK(h && ms_out && iters > 0, "bad argument");
-  const size_t mk = h->arena.mark();
+  ArenaScope arena_scope(h->arena);
   Ctx c = h->ctx();
   ConvW w;
   w.N = N; w.Cin = C0 + C1; w.KH = k; w.KW = k; w.Cpad = round_up(C0 + C1, 32); w.Npad = round_up(N, 128);
@@ -716,7 +729,6 @@ extern "C" int cd_op_bench_conv(cd_handle h, int B, int H, int W, int C0, int C1
   HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
   *ms_out = ms / iters;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  h->arena.release(mk);
   CD_API_END
 }
 

@@ -101,6 +101,9 @@ __device__ inline uint4 pack8(const float* f) {
 }
 
 __device__ inline float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// <= 1 ulp exp: the fp32 path and the fp32 time-embedding MLP (the pixel 'ddim' chain amplifies every deviation from
+// the reference's fp32 arithmetic by 4-5 orders of magnitude)
+__device__ inline float silu_acc(float x) { return x / (1.0f + expf(-x)); }
 // exact-erf GELU (reference: F.gelu default, attention.py:44)
 __device__ inline float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

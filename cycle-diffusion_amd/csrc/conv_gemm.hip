@@ -496,13 +496,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
 template <int BM, int BN, int BK, int WM, int WN, int NSTAGE>
 void launch_cfg(hipStream_t st, const ConvGemmParams& p) {
   using T = TileCfg<BM, BN, BK, WM, WN, NSTAGE>;
-  static bool attr_set = false;
+  static std::once_flag attr_once;  // engines on several host threads launch the same instantiation
   auto kern = k_conv_gemm<BM, BN, BK, WM, WN, NSTAGE>;
-  if (!attr_set) {
+  std::call_once(attr_once, [&]() {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   T::LDS_BYTES));
-    attr_set = true;
-  }
+  });
   const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
   const int split = p.splitk > 1 ? p.splitk : 1;
   if (split > 1) {
@@ -640,8 +639,10 @@ KernelProfiler::~KernelProfiler() { for (auto e : events) (void)hipEventDestroy(
 // ---- online autotuner: the engine replays the same few dozen contraction shapes hundreds of times, so
 // the first time a shape is seen every tile configuration is timed on it (HIP events, output redirected
 // to a scratch buffer so in-place residual updates are not disturbed) and the fastest is remembered.
-// Every configuration accumulates each output element in the same k order, so the choice never changes
-// a result bit.
+// Every tile configuration accumulates each output element in the same k order, so the choice of TILE never changes a
+// result bit. A split-K factor does (it sums per-range fp32 partials): split factors therefore come only from the
+// shipped / cached table (tune_gfx950.txt, CYCLEDIFF_TUNE_CACHE), identical for every process and rank; online tuning
+// of an unseen shape tries split = 1 only, unless CYCLEDIFF_TUNE_SPLITK=1 (the mode the shipped table is made in).
 ConvTuner g_conv_tuner;
 
 namespace {
@@ -717,6 +718,7 @@ int tuned_config(hipStream_t st, const ConvGemmParams& p, bool k64) {
   const int64_t t128 = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 128) * p.nbatch;
   const int nk = p.Ktot / (k64 ? 64 : 32);
   static const int kSplits[] = {1, 2, 3, 4, 6, 8, 12, 16};
+  static const bool tune_splitk = [] { const char* e = getenv("CYCLEDIFF_TUNE_SPLITK"); return e && e[0] == '1'; }();
   // short-K contractions (1x1 convs / linears) also try the BK=32 variants: half the LDS per stage, so
   // twice the resident blocks to hide the prologue / epilogue of a 5-10 step K loop
   const int nbk = (k64 && p.Ktot <= 1280) ? 2 : 1;
@@ -727,6 +729,7 @@ int tuned_config(hipStream_t st, const ConvGemmParams& p, bool k64) {
     const int split = kSplits[si];
     const bool use64 = k64 && bi == 0;
     if (bi == 1 && split > 1) continue;
+    if (split > 1 && !tune_splitk) continue;
     if (p.act == ACT_GEGLU && c.TN < 64) continue;
     if (c.BM >= 256 && p.M < 256) continue;
     const int64_t tiles = (int64_t)ceil_div(p.M, c.BM) * ceil_div(p.N, c.BN) * p.nbatch;

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_vec_linear(const float* __restrict__ x,
         if (v < nv) {
           const f32x4 wv = __builtin_nontemporal_load((const f32x4*)wr + v);
           f32x4 xv = *((const f32x4*)xr + v);
-          if (silu_in) { xv[0] = silu_f(xv[0]); xv[1] = silu_f(xv[1]); xv[2] = silu_f(xv[2]); xv[3] = silu_f(xv[3]); }
+          if (silu_in) { xv[0] = silu_acc(xv[0]); xv[1] = silu_acc(xv[1]); xv[2] = silu_acc(xv[2]); xv[3] = silu_acc(xv[3]); }
           a4[u] += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
         }
       }
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_vec_linear(const float* __restrict__ x,
   } else {
     for (int k = lane; k < K; k += 64) {
       float xv = xr[k];
-      if (silu_in) xv = silu_f(xv);
+      if (silu_in) xv = silu_acc(xv);
       acc += xv * wr[k];
     }
   }
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_vec_linear(const float* __restrict__ x,
   for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
   if (lane == 0) {
     float v = acc + (bias ? bias[n] : 0.f);
-    if (silu_out) v = silu_f(v);
+    if (silu_out) v = silu_acc(v);
     y[(int64_t)b * ldy + n] = v;
   }
 }

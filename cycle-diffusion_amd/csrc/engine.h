@@ -31,10 +31,12 @@ class Arena {
   size_t cap_ = 0, off_ = 0, high_ = 0;
 };
 
-struct Act {  // NHWC bf16 activation view
+struct Act {  // NHWC activation view: 16-bit elements, or fp32 when f32 is set (precision CD_PREC_F32)
   bf16_t* p = nullptr;
   int B = 0, H = 0, W = 0, C = 0;
   int ld = 0;  // pixel stride (elements)
+  bool f32 = false;
+  float* pf() const { return (float*)p; }
   // GroupNorm statistics of this tensor, written by the conv epilogue that produced it
   // ([B*H*W/32][2][C] fp32, ConvGemmParams::stats); stats_buf = storage, stats = valid content
   float* stats = nullptr;
@@ -43,8 +45,9 @@ struct Act {  // NHWC bf16 activation view
 };
 
 // ------------------------------------------------------------------ parameters
-struct ConvW {  // packed conv / linear weight: bf16 [Npad][KH*KW*Cpad], fp32 bias[N]
+struct ConvW {  // packed conv / linear weight: 16-bit (or fp32 when f32) [Npad][KH*KW*Cpad], fp32 bias[N]
   bf16_t* w = nullptr;
+  bool f32 = false;
   float* b = nullptr;
   int N = 0, Cin = 0, Cpad = 0, KH = 1, KW = 1, Npad = 0;
   bool geglu = false;
@@ -75,6 +78,7 @@ struct ParamDecl {
 class ParamStore {
  public:
   ~ParamStore();
+  bool f32 = false;  // matrices are packed as fp32 (set by the network before it declares anything)
   // allocate packed storage
   ConvW* new_conv(int N, int Cin, int KH, int KW, bool bias, bool geglu = false);
   float* new_vec(int n, float init = 0.f);
@@ -114,6 +118,7 @@ struct Ctx {
   const bf16_t* zeros = nullptr;
   float* gn_partial = nullptr;  // [B][S][G][2] scratch, sized for the largest GroupNorm
   size_t gn_partial_floats = 0;
+  bool f32 = false;             // the running network executes in fp32 (Net::f32)
 };
 
 // shared building blocks -------------------------------------------------------------------
@@ -143,6 +148,12 @@ Act groupnorm_fwd(Ctx& c, const GNW& w, const Act& x, const Act* x2, bool silu, 
 struct LNW { float* g = nullptr; float* b = nullptr; int C = 0; };
 Act layernorm_fwd(Ctx& c, const LNW& w, const Act& x);
 
+// 2x2 average pool / nearest x2 upsample of a dense activation (resblock_updown, improved_ddpm/unet.py:104-135)
+Act avgpool2_fwd(Ctx& c, const Act& x);
+Act upsample2_fwd(Ctx& c, const Act& x);
+// fp32 path: softmax(scale q k^T) v + obias with q | k in one token-major tensor and v in another
+Act attention_f32_fwd(Ctx& c, const Act& qk, const Act& v, int H, int D, float scale, const float* obias);
+
 // multi-head attention on token-major activations; vt is [B][H*D][Tpad]
 Act attention_fwd(Ctx& c, const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* vt, int B,
                   int H, int Tq, int Tk, int Tpad, int D, float scale, int Himg, int Wimg);
@@ -153,6 +164,7 @@ class Net {
   virtual ~Net() {}
   ParamStore params;
   cd_net_desc desc;
+  bool f32 = false;  // desc.precision == CD_PREC_F32
   virtual int kind() const = 0;
 };
 

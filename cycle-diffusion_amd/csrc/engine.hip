@@ -40,7 +40,8 @@ ConvW* ParamStore::new_conv(int N, int Cin, int KH, int KW, bool bias, bool gegl
   c->N = N; c->Cin = Cin; c->KH = KH; c->KW = KW; c->geglu = geglu;
   c->Cpad = round_up(Cin, 32);
   c->Npad = round_up(N, 128);
-  c->w = (bf16_t*)dmalloc((size_t)c->Npad * c->Ktot() * sizeof(bf16_t));
+  c->f32 = f32;
+  c->w = (bf16_t*)dmalloc((size_t)c->Npad * c->Ktot() * (f32 ? sizeof(float) : sizeof(bf16_t)));
   if (bias) c->b = (float*)dmalloc((size_t)c->Npad * sizeof(float));
   return c;
 }
@@ -115,7 +116,8 @@ void ParamStore::mat_f32(const std::string& name, float* dst, int N, int K, int 
 }
 
 // repack with a row map: dst row j <- src row src_base + (j/grp)*grp_stride + j%grp
-__global__ void k_pack_rows(const float* __restrict__ w, bf16_t* __restrict__ out, int rows, int Cin,
+template <typename OutT>
+__global__ void k_pack_rows(const float* __restrict__ w, OutT* __restrict__ out, int rows, int Cin,
                             int KH, int KW, int Cpad, int dst_row0, int src_base, int grp,
                             int grp_stride, int geglu, int Ntot) {
   const int64_t total = (int64_t)rows * KH * KW * Cpad;
@@ -134,7 +136,9 @@ __global__ void k_pack_rows(const float* __restrict__ w, bf16_t* __restrict__ ou
     const int src = src_base + (jj / grp) * grp_stride + (jj % grp);
     float v = 0.f;
     if (c < Cin) v = w[(((int64_t)src * Cin + c) * KH + r) * KW + s];
-    out[((int64_t)(dst_row0 + j) * KH * KW + (int64_t)r * KW + s) * Cpad + c] = f2bf(v);
+    const int64_t o = ((int64_t)(dst_row0 + j) * KH * KW + (int64_t)r * KW + s) * Cpad + c;
+    if constexpr (sizeof(OutT) == 4) out[o] = v;
+    else out[o] = f2bf(v);
   }
 }
 
@@ -173,9 +177,12 @@ void ParamStore::load(hipStream_t st, const std::string& name, const float* host
       const int64_t total = (int64_t)t.rows * c->KH * c->KW * c->Cpad;
       int grid = (int)((total + 255) / 256);
       if (grid > 8192) grid = 8192;
-      hipLaunchKernelGGL(k_pack_rows, dim3(grid), dim3(256), 0, st, staging_, c->w, t.rows, c->Cin, c->KH,
-                         c->KW, c->Cpad, t.dst_row0, t.src_base, t.grp, t.grp_stride, t.geglu ? 1 : 0,
-                         c->N);
+      if (c->f32)
+        hipLaunchKernelGGL(k_pack_rows<float>, dim3(grid), dim3(256), 0, st, staging_, (float*)c->w, t.rows, c->Cin,
+                           c->KH, c->KW, c->Cpad, t.dst_row0, t.src_base, t.grp, t.grp_stride, t.geglu ? 1 : 0, c->N);
+      else
+        hipLaunchKernelGGL(k_pack_rows<bf16_t>, dim3(grid), dim3(256), 0, st, staging_, c->w, t.rows, c->Cin, c->KH,
+                           c->KW, c->Cpad, t.dst_row0, t.src_base, t.grp, t.grp_stride, t.geglu ? 1 : 0, c->N);
     } else {
       // small: map on the host
       const int K = (t.kind == PackTarget::MATRIX_F32) ? t.K : 1;
@@ -209,15 +216,17 @@ int ParamStore::missing(std::string* first) const {
 
 // ------------------------------------------------------------------ building blocks
 Act alloc_act(Ctx& c, int B, int H, int W, int C, bool with_stats) {
-  Act a; a.B = B; a.H = H; a.W = W; a.C = C; a.ld = C;
-  a.p = (bf16_t*)c.arena->alloc((size_t)B * H * W * C * sizeof(bf16_t));
-  if (with_stats && ((H * W) % 32) == 0)
+  Act a; a.B = B; a.H = H; a.W = W; a.C = C; a.ld = C; a.f32 = c.f32;
+  a.p = (bf16_t*)c.arena->alloc((size_t)B * H * W * C * (c.f32 ? sizeof(float) : sizeof(bf16_t)));
+  if (!c.f32 && with_stats && ((H * W) % 32) == 0)
     a.stats_buf = (float*)c.arena->alloc((size_t)(B * H * W / 32) * 2 * C * sizeof(float));
   return a;
 }
 
 Act conv_fwd(Ctx& c, const ConvW& w, const Act& x, const Act* x2, const ConvOpts& o) {
   ConvGemmParams p;
+  CD_CHECK(w.f32 == c.f32 && x.f32 == c.f32 && (!x2 || x2->f32 == c.f32) && (!o.resid || o.resid->f32 == c.f32),
+           "conv: operand precision does not match the running network");
   p.src0 = x.p; p.C0 = round_up(x.C, 32); p.ld0 = x.ld;
   if (x2) {
     CD_CHECK(x2->B == x.B && x2->H == x.H && x2->W == x.W, "conv: concat sources differ in shape");
@@ -241,11 +250,11 @@ Act conv_fwd(Ctx& c, const ConvW& w, const Act& x, const Act* x2, const ConvOpts
   p.rowvec = o.rowvec; p.rowvec_ld = o.rowvec_ld; p.rows_per_vec = o.rows_per_vec;
   p.act = w.geglu ? ACT_GEGLU : o.act;
   const int Nout = w.geglu ? w.N / 2 : w.N;
-  Act y; y.B = x.B; y.H = p.Hout; y.W = p.Wout; y.C = Nout;
+  Act y; y.B = x.B; y.H = p.Hout; y.W = p.Wout; y.C = Nout; y.f32 = c.f32;
   if (o.out) { y.p = (bf16_t*)o.out; y.ld = o.out_ld; }
   else {
     y.ld = Nout;
-    y.p = (bf16_t*)c.arena->alloc((size_t)p.M * Nout * (o.out_f32 ? 4 : 2));
+    y.p = (bf16_t*)c.arena->alloc((size_t)p.M * Nout * ((o.out_f32 || c.f32) ? 4 : 2));
   }
   if (o.resid) {
     CD_CHECK(o.resid->rows() == p.M && o.resid->C == Nout, "conv: residual shape mismatch");
@@ -253,6 +262,11 @@ Act conv_fwd(Ctx& c, const ConvW& w, const Act& x, const Act* x2, const ConvOpts
   }
   p.out = y.p; p.out_ld = y.ld; p.out_f32 = o.out_f32 ? 1 : 0;
   p.zeros = c.zeros; p.tile = o.tile;
+  if (c.f32) {
+    p.out_f32 = 1;
+    launch_conv_gemm_f32(c.st, p);
+    return y;
+  }
   if (!w.geglu && !o.out_f32 && ((p.Hout * p.Wout) % 32) == 0) {
     if (o.out && o.out_stats) y.stats_buf = o.out_stats;
     else if (!o.out && o.want_stats)
@@ -275,6 +289,14 @@ Act groupnorm_fwd(Ctx& c, const GNW& w, const Act& x, const Act* x2, bool silu, 
   p.film = film; p.film_ld = film_ld; p.silu = silu ? 1 : 0;
   Act y = alloc_act(c, x.B, x.H, x.W, C);
   p.y = y.p;
+  if (c.f32) {
+    CD_CHECK(x.f32 && (!x2 || x2->f32), "groupnorm: operand precision");
+    const size_t mk = c.arena->mark();
+    void* ws = c.arena->alloc(groupnorm_f32_workspace(p.B, p.HW, C));
+    launch_groupnorm_f32(c.st, p, ws);
+    c.arena->release(mk);  // stream order keeps the scratch alive until the three kernels have run
+    return y;
+  }
   p.S = groupnorm_slabs(p.B, p.HW, C);
   const size_t part_floats = round_up((size_t)p.B * p.S * p.G * 2, (size_t)64);
   CD_CHECK(part_floats + (size_t)p.B * 2 * C <= c.gn_partial_floats, "groupnorm: workspace too small");
@@ -288,7 +310,30 @@ Act groupnorm_fwd(Ctx& c, const GNW& w, const Act& x, const Act* x2, bool silu, 
   return y;
 }
 
+Act avgpool2_fwd(Ctx& c, const Act& x) {
+  CD_CHECK(x.ld == x.C, "avgpool: dense input expected");
+  Act y = alloc_act(c, x.B, x.H / 2, x.W / 2, x.C);
+  if (c.f32) launch_avgpool2_f32(c.st, x.pf(), y.pf(), x.B, x.H, x.W, x.C);
+  else launch_avgpool2(c.st, x.p, y.p, x.B, x.H, x.W, x.C);
+  return y;
+}
+Act upsample2_fwd(Ctx& c, const Act& x) {
+  CD_CHECK(x.ld == x.C, "upsample: dense input expected");
+  Act y = alloc_act(c, x.B, x.H * 2, x.W * 2, x.C);
+  if (c.f32) launch_upsample2_f32(c.st, x.pf(), y.pf(), x.B, x.H, x.W, x.C);
+  else launch_upsample2(c.st, x.p, y.p, x.B, x.H, x.W, x.C);
+  return y;
+}
+Act attention_f32_fwd(Ctx& c, const Act& qk, const Act& v, int H, int D, float scale, const float* obias) {
+  CD_CHECK(c.f32 && qk.f32 && v.f32 && qk.C == 2 * H * D && v.C == H * D, "attention_f32: operands");
+  Act o = alloc_act(c, qk.B, qk.H, qk.W, H * D);
+  launch_attention_f32(c.st, qk.pf(), qk.ld, qk.pf() + H * D, qk.ld, v.pf(), v.ld, o.pf(), o.ld, qk.B, H,
+                       qk.H * qk.W, D, scale, obias);
+  return o;
+}
+
 Act layernorm_fwd(Ctx& c, const LNW& w, const Act& x) {
+  CD_CHECK(!c.f32, "layernorm: the fp32 path covers the pixel-space U-Nets only (no transformer blocks)");
   CD_CHECK(x.C == w.C, "layernorm: channels");
   Act y = alloc_act(c, x.B, x.H, x.W, x.C);
   launch_layernorm(c.st, x.p, x.ld, y.p, y.ld, (int)x.rows(), x.C, w.g, w.b, 1e-5f);
@@ -297,6 +342,7 @@ Act layernorm_fwd(Ctx& c, const LNW& w, const Act& x) {
 
 Act attention_fwd(Ctx& c, const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* vt, int B,
                   int H, int Tq, int Tk, int Tpad, int D, float scale, int Himg, int Wimg) {
+  CD_CHECK(!c.f32, "attention: 16-bit kernel called on the fp32 path");
   Act o = alloc_act(c, B, Himg, Wimg, H * D);
   AttnParams p;
   p.q = q; p.k = k; p.vt = vt; p.o = o.p;

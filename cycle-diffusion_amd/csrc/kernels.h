@@ -211,6 +211,20 @@ void launch_gather_eot(hipStream_t st, const bf16_t* x, const int* ids, bf16_t* 
 // token + position embedding lookup: out[b][l][:] = tok[ids[b][l]][:] + pos[l][:] (fp32 tables -> 16-bit rows)
 void launch_embed_tokens(hipStream_t st, const int* ids, const float* tok, const float* pos, bf16_t* out, int B,
                          int L, int D, int vocab);
+// ---------------------------------------------------------------- fp32 execution path (f32_path.hip)
+// The same parameter structs with every activation / weight / output pointer holding fp32 data and every `ld` counted
+// in floats (precision CD_PREC_F32: pixel-space DDPMs). Fixed tile shapes, no autotuner, no split-K.
+void launch_conv_gemm_f32(hipStream_t st, const ConvGemmParams& p);
+size_t groupnorm_f32_workspace(int B, int HW, int C);
+void launch_groupnorm_f32(hipStream_t st, const GroupNormParams& p, void* workspace);
+// softmax(scale * q k^T) v + obias on token-major fp32 tensors, head h at column h*D
+void launch_attention_f32(hipStream_t st, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                          float* o, int ldo, int B, int H, int T, int D, float scale, const float* obias);
+void launch_nchw_to_nhwc_f32(hipStream_t st, const float* x, float* y, int B, int C, int HW, int Cpad, float scale,
+                             float shift);
+void launch_avgpool2_f32(hipStream_t st, const float* x, float* y, int B, int H, int W, int C);
+void launch_upsample2_f32(hipStream_t st, const float* x, float* y, int B, int H, int W, int C);
+
 void launch_copy_strided_bf16(hipStream_t st, const bf16_t* src, int lds, bf16_t* dst, int ldd,
                               int64_t rows, int cols);
 

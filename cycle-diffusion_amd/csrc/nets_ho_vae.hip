@@ -105,6 +105,14 @@ Act at_fwd(Ctx& c, const AtW& a, const Act& x) {
   ConvOpts p0; p0.pad = 0;
   Act n = groupnorm_fwd(c, a.norm, x, nullptr, false);
   Act qk = conv_fwd(c, *a.qk, n, nullptr, p0);  // [B*T][2C]
+  if (c.f32) {  // fp32 path (Ho-DDPM in CD_PREC_F32): single head of width C
+    Act v = conv_fwd(c, *a.v, n, nullptr, p0);
+    Act o = attention_f32_fwd(c, qk, v, 1, C, 1.0f / sqrtf((float)C), a.vbias);
+    ConvOpts po; po.pad = 0; po.resid = &x; po.out = out.p; po.out_ld = out.ld;
+    conv_fwd(c, *a.proj, o, nullptr, po);
+    c.arena->release(mk);
+    return out;
+  }
   const int Tpad = round_up(T, 64);
   bf16_t* vt = (bf16_t*)c.arena->alloc((size_t)B * C * Tpad * 2);
   if (Tpad != T) HIP_CHECK(hipMemsetAsync(vt, 0, (size_t)B * C * Tpad * 2, c.st));
@@ -168,6 +176,7 @@ class VAEKL : public VAE {
 
 VAEKL::VAEKL(const cd_net_desc& d) {
   desc = d;
+  CD_CHECK(d.precision == CD_PREC_16, "the KL autoencoder runs in the 16-bit format only");
   ch_ = d.model_channels; nres_ = d.num_res_blocks; nlev_ = d.n_mult;
   for (int i = 0; i < nlev_; ++i) mult_.push_back(d.channel_mult[i]);
   z_channels = d.z_channels; embed_ = d.embed_dim; in_ch_ = d.in_channels; out_ch_ = d.out_channels;
@@ -282,6 +291,8 @@ class UNetHo : public UNet {
 
 UNetHo::UNetHo(const cd_net_desc& d) {
   desc = d;
+  f32 = d.precision == CD_PREC_F32;
+  params.f32 = f32;
   ch_ = d.model_channels; nres_ = d.num_res_blocks; nlev_ = d.n_mult; temb_ch_ = 4 * ch_;
   image_size = d.image_size; out_channels = d.out_channels; in_cpad = round_up(d.in_channels, 32);
   CD_CHECK(ch_ % 32 == 0, "ch must be a multiple of 32");
@@ -355,6 +366,7 @@ UNetHo::UNetHo(const cd_net_desc& d) {
 
 void UNetHo::forward(Ctx& c, const UNetIO& io) {
   const size_t mk0 = c.arena->mark();
+  c.f32 = f32;
   const int B = io.B, R = image_size;
   const int tB = io.t_shared ? 1 : B;
   float* sinu = (float*)c.arena->alloc((size_t)tB * ch_ * 4);
@@ -367,7 +379,7 @@ void UNetHo::forward(Ctx& c, const UNetIO& io) {
   launch_vec_linear(c.st, emb, temb_ch_, te_.proj_w, te_.proj_b, proj, te_.proj_total, tB, temb_ch_,
                     te_.proj_total, 1, 0);
   const int pl = te_.proj_total;
-  Act x; x.p = (bf16_t*)io.xin; x.B = B; x.H = R; x.W = R; x.C = in_cpad; x.ld = in_cpad;
+  Act x; x.p = (bf16_t*)io.xin; x.B = B; x.H = R; x.W = R; x.C = in_cpad; x.ld = in_cpad; x.f32 = f32;
   ConvOpts o3; o3.want_stats = true;
   std::vector<Act> hs;
   hs.push_back(conv_fwd(c, *cin_, x, nullptr, o3));
@@ -398,6 +410,7 @@ void UNetHo::forward(Ctx& c, const UNetIO& io) {
   ConvOpts oo; oo.out_f32 = true; oo.out = io.out; oo.out_ld = io.out_ld;
   conv_fwd(c, *cout_, n, nullptr, oo);
   c.arena->release(mk0);
+  c.f32 = false;
 }
 
 }  // namespace

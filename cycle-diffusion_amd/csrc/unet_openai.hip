@@ -167,6 +167,9 @@ int UNetOpenAI::add_ab(const std::string& pfx, int C, int heads) {
 
 UNetOpenAI::UNetOpenAI(const cd_net_desc& d) {
   desc = d;
+  f32 = d.precision == CD_PREC_F32;
+  params.f32 = f32;
+  CD_CHECK(!(f32 && d.use_spatial_transformer), "CD_PREC_F32 covers U-Nets without SpatialTransformer blocks");
   mc_ = d.model_channels; hidden_ = 4 * mc_;
   image_size = d.image_size; out_channels = d.out_channels;
   in_cpad = round_up(d.in_channels, 32);
@@ -295,18 +298,12 @@ Act UNetOpenAI::res_fwd(Ctx& c, const ResW& r, const Act& x, const Act* x2, cons
   bool up_in_conv = false;
   if (r.down) {
     CD_CHECK(!x2, "resblock_updown with concat input is not produced by the reference");
-    Act hp = alloc_act(c, x.B, Ho, Wo, r.cin);
-    launch_avgpool2(c.st, h.p, hp.p, x.B, x.H, x.W, r.cin);
-    h = hp;
-    Act xp = alloc_act(c, x.B, Ho, Wo, r.cin);
-    launch_avgpool2(c.st, x.p, xp.p, x.B, x.H, x.W, r.cin);
-    xs = xp; xs2 = nullptr;
+    h = avgpool2_fwd(c, h);
+    xs = avgpool2_fwd(c, x); xs2 = nullptr;
   } else if (r.up) {
     CD_CHECK(!x2, "resblock_updown with concat input is not produced by the reference");
     up_in_conv = true;
-    Act xu = alloc_act(c, x.B, Ho, Wo, r.cin);
-    launch_upsample2(c.st, x.p, xu.p, x.B, x.H, x.W, r.cin);
-    xs = xu; xs2 = nullptr;
+    xs = upsample2_fwd(c, x); xs2 = nullptr;
   }
   ConvOpts o1; o1.up = up_in_conv; o1.want_stats = true;
   const float* pr = proj + r.emb_off;
@@ -418,6 +415,14 @@ Act UNetOpenAI::ab_fwd(Ctx& c, const ABW& a, const Act& x) {
   ConvOpts p0; p0.pad = 0;
   Act n = groupnorm_fwd(c, a.norm, x, nullptr, false);
   Act qk = conv_fwd(c, *a.qk, n, nullptr, p0);
+  if (c.f32) {  // fp32 path: V as ordinary tokens, its bias added to the output (rows of P sum to 1)
+    Act v = conv_fwd(c, *a.v, n, nullptr, p0);
+    Act o = attention_f32_fwd(c, qk, v, a.heads, a.dh, 1.0f / sqrtf((float)a.dh), a.vbias);
+    ConvOpts po; po.pad = 0; po.resid = &x; po.out = out.p; po.out_ld = out.ld;
+    conv_fwd(c, *a.proj, o, nullptr, po);
+    c.arena->release(mk);
+    return out;
+  }
   const int Tpad = round_up(T, 64);
   bf16_t* vt = (bf16_t*)c.arena->alloc((size_t)B * C * Tpad * 2);
   if (Tpad != T) HIP_CHECK(hipMemsetAsync(vt, 0, (size_t)B * C * Tpad * 2, c.st));
@@ -457,6 +462,7 @@ Act UNetOpenAI::run_block(Ctx& c, const Block& b, Act h, const Act* skip, const 
 
 void UNetOpenAI::forward(Ctx& c, const UNetIO& io) {
   const size_t mk0 = c.arena->mark();
+  c.f32 = f32;
   const int B = io.B, R = image_size;
   // ---- time embedding: sinusoid -> Linear -> SiLU -> Linear, then every ResBlock's
   //      emb_layers (SiLU -> Linear) in one launch (openaimodel.py:506-511,723-724,263)
@@ -471,7 +477,7 @@ void UNetOpenAI::forward(Ctx& c, const UNetIO& io) {
   launch_vec_linear(c.st, emb, hidden_, te_.proj_w, te_.proj_b, proj, te_.proj_total, tB, hidden_,
                     te_.proj_total, 1, 0);
   const int proj_ld = te_.proj_total;
-  Act x; x.p = (bf16_t*)io.xin; x.B = B; x.H = R; x.W = R; x.C = in_cpad; x.ld = in_cpad;
+  Act x; x.p = (bf16_t*)io.xin; x.B = B; x.H = R; x.W = R; x.C = in_cpad; x.ld = in_cpad; x.f32 = f32;
   std::vector<Act> hs;
   Act h = x;
   for (const Block& b : in_blocks_) {
@@ -487,6 +493,7 @@ void UNetOpenAI::forward(Ctx& c, const UNetIO& io) {
   ConvOpts oo; oo.out_f32 = true; oo.out = io.out; oo.out_ld = io.out_ld;
   conv_fwd(c, *out_conv_, hn, nullptr, oo);
   c.arena->release(mk0);
+  c.f32 = false;
 }
 
 }  // namespace

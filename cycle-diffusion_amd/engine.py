@@ -12,8 +12,9 @@ from ._ffi import NetDesc, check, ptr
 def make_desc(kind, *, image_size, in_channels, out_channels, model_channels, num_res_blocks, channel_mult,
               attn=(), num_heads=-1, num_head_channels=-1, use_spatial_transformer=False, context_dim=0,
               transformer_depth=1, use_scale_shift_norm=False, resblock_updown=False, conv_resample=True,
-              z_channels=0, embed_dim=0, double_z=False):
+              z_channels=0, embed_dim=0, double_z=False, precision=_ffi.CD_PREC_16):
     d = NetDesc()
+    d.precision = int(precision)
     d.kind = kind
     d.image_size = image_size
     d.in_channels, d.out_channels = in_channels, out_channels
@@ -84,19 +85,20 @@ def bert_xtransformer_desc(width=1280, layers=32, vocab=30522, positions=77, hea
                      num_head_channels=dim_head, context_dim=4 * width)
 
 
-def afhq_iddpm_desc(image_size=256):
+def afhq_iddpm_desc(image_size=256, precision=_ffi.CD_PREC_16):
     """improved_ddpm/script_util.py:5-22,45-104 (AFHQ_DICT; learn_sigma -> 6 output channels)"""
     return make_desc(_ffi.CD_NET_UNET_OPENAI, image_size=image_size, in_channels=3, out_channels=6,
                      model_channels=128, num_res_blocks=1, channel_mult=(1, 1, 2, 2, 4, 4),
                      attn=(image_size // 16,), num_heads=4, num_head_channels=64,
-                     use_scale_shift_norm=True, resblock_updown=True)
+                     use_scale_shift_norm=True, resblock_updown=True, precision=precision)
 
 
-def ho_ddpm_desc(image_size, ch, ch_mult, num_res_blocks, attn_resolutions, in_channels=3, out_ch=3):
+def ho_ddpm_desc(image_size, ch, ch_mult, num_res_blocks, attn_resolutions, in_channels=3, out_ch=3,
+                 precision=_ffi.CD_PREC_16):
     """ddpm/diffusion.py:192-205 (config.model.*)"""
     return make_desc(_ffi.CD_NET_UNET_HO, image_size=image_size, in_channels=in_channels, out_channels=out_ch,
                      model_channels=ch, num_res_blocks=num_res_blocks, channel_mult=tuple(ch_mult),
-                     attn=tuple(attn_resolutions))
+                     attn=tuple(attn_resolutions), precision=precision)
 
 
 class Engine:

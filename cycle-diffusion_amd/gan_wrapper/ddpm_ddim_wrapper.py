@@ -3,6 +3,10 @@
 class_label=None) -> z [B, es_steps*C*R*R], forward(z, class_label=None) -> img in [0,1],
 attributes .resolution .latent_dim .enforce_class_input.
 
+Precision: `[gan] precision = fp32` (default) runs the network in fp32 end to end on the engine's fp32 path - what the
+reference computes in (use_fp16=False) and what the 'ddim' chain needs to be reproducible (DESIGN.md §5);
+`precision = fp16` selects the 16-bit engine (about 6x the throughput; fine for sample_type 'ddpm').
+
 Unlike the reference, decode is batched: its 'ddim' branch compares [B,1,1,1] tensors and only runs
 at batch 1 (ddpm_ddim_wrapper.py:216; README.md:254); per-sample results are identical.
 """
@@ -10,7 +14,7 @@ import os
 
 import torch
 
-from .. import schedule
+from .. import _ffi, schedule
 from ..engine import afhq_iddpm_desc, ho_ddpm_desc
 from ..runtime import get_engine, load_or_init_weights
 
@@ -28,13 +32,16 @@ MODEL_TYPES = {
 }
 
 
-def _desc(arch):
+PRECISIONS = {"fp32": _ffi.CD_PREC_F32, "fp16": _ffi.CD_PREC_16, "16": _ffi.CD_PREC_16}
+
+
+def _desc(arch, precision=_ffi.CD_PREC_F32):
     if arch == "ho256":
-        return ho_ddpm_desc(256, 128, (1, 1, 2, 2, 4, 4), 2, (16,))
+        return ho_ddpm_desc(256, 128, (1, 1, 2, 2, 4, 4), 2, (16,), precision=precision)
     if arch == "iddpm256":
-        return afhq_iddpm_desc(256)
+        return afhq_iddpm_desc(256, precision=precision)
     if arch == "toy32":
-        return ho_ddpm_desc(32, 32, (1, 2, 2), 1, (16,))
+        return ho_ddpm_desc(32, 32, (1, 2, 2), 1, (16,), precision=precision)
     raise NotImplementedError(arch)
 
 
@@ -42,8 +49,11 @@ class DDPMDDIMWrapper(torch.nn.Module):
 
     def __init__(self, source_model_type, sample_type, custom_steps, es_steps, source_model_path=None,
                  refine_steps=0, refine_iterations=1, eta=None, t_0=None, enforce_class_input=None, device=None,
-                 noise_on_cpu=False):
+                 noise_on_cpu=False, precision="fp32", net_desc=None):
         super().__init__()
+        if str(precision) not in PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
+        self.precision = str(precision)
         # parity runs draw every noise tensor on the CPU, one tensor per reference draw, in the reference's order
         self.noise_on_cpu = bool(noise_on_cpu)
         self.enforce_class_input = enforce_class_input
@@ -62,9 +72,14 @@ class DDPMDDIMWrapper(torch.nn.Module):
         arch, default_path = MODEL_TYPES[source_model_type]
         if default_path is not None and source_model_type != "ffhq256":
             assert source_model_path is None
+        if arch == "iddpm256" and default_path is None and net_desc is None:
+            # afhq*: the reference asserts a path is given (ddpm_ddim_wrapper.py:60-74)
+            from ..runtime import synthetic_allowed
+            assert source_model_path is not None or synthetic_allowed(), \
+                "%s needs source_model_path (or CYCLEDIFF_SYNTHETIC_WEIGHTS=1)" % source_model_type
         path = source_model_path or default_path
         self.engine = get_engine(device)
-        d = _desc(arch)
+        d = net_desc if net_desc is not None else _desc(arch, PRECISIONS[self.precision])
         self.net = self.engine.create_net(d)
         self.weights_origin = load_or_init_weights(self.engine, path, {self.net: ""},
                                                    seed=abs(hash_str(source_model_type)) % 1000)

@@ -6,10 +6,13 @@ encode(image, encode_text) -> z_ensemble and forward(z_ensemble, original_img, e
 decode_text) -> img contracts, same ensemble ordering (trial -> encoder scale -> skip_steps, then
 decoder scales) and z layout torch.stack(z_list, dim=1).view(bsz, -1).
 
-Conditioning enters through `cond_stage` (a callable list[str] -> [B, 77, context_dim]):
-`[gan] text_encoder = clip` runs the CLIP text transformer on the engine (text_encoders.py); otherwise a
-deterministic stand-in embedding is used and SAYS SO in its name. The DirectionalCLIP ranker and the LDM BERT
-encoder stay out of scope.
+Conditioning enters through `cond_stage` (a callable list[str] -> [B, 77, context_dim]). With a real checkpoint
+the text encoder stored in it is used, as in the reference: CLIP ViT-L/14 text (SD) or the BERT-tokenizer
+x-transformer (LDM), both on the engine (text_encoders.py), and a missing tokenizer vocabulary is an error.
+`[gan] text_encoder = clip | bert` forces one. Only in synthetic-weight runs (CYCLEDIFF_SYNTHETIC_WEIGHTS=1, no
+checkpoint) a deterministic stand-in embedding is used, and SAYS SO in its name. `[gan] ranker = directional_clip`
+is the reference's DirectionalCLIP on the engine (ranker.py); its ViT-B/32 weights come from `ranker_path` /
+CYCLEDIFF_CLIP_RANKER (the `clip.load("ViT-B/32")` state_dict saved with torch.save).
 
 Ensemble members that share (guidance scale, skip) differ only in their noise: they are folded into the batch
 dimension of ONE engine call - same draws, same member order, larger GEMMs.
@@ -21,7 +24,7 @@ import torch
 
 from .. import _ffi, schedule
 from ..engine import kl_f8_vae_desc, ldm_text_unet_desc, sd_v1_unet_desc
-from ..runtime import get_engine, load_or_init_weights, read_checkpoint
+from ..runtime import get_engine, load_or_init_weights, read_checkpoint, synthetic_allowed
 
 
 class StandInTextEmbedder:
@@ -53,7 +56,7 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
     def __init__(self, source_model_type, custom_steps, eta, white_box_steps, skip_steps,
                  encoder_unconditional_guidance_scales=None, decoder_unconditional_guidance_scales=None,
                  n_trials=None, cond_stage=None, ranker=None, device=None, text_encoder=None,
-                 noise_on_cpu=False, fold_ensemble=True):
+                 noise_on_cpu=False, fold_ensemble=True, ranker_path=None):
         super().__init__()
         self.encoder_unconditional_guidance_scales = encoder_unconditional_guidance_scales
         self.decoder_unconditional_guidance_scales = decoder_unconditional_guidance_scales
@@ -75,20 +78,37 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
         ckpt_sd = read_checkpoint(ckpt)
         self.weights_origin = load_or_init_weights(self.engine, ckpt, {
             self.unet: "model.diffusion_model.", self.vae: "first_stage_model."}, state_dict=ckpt_sd)
+        if cond_stage is None and text_encoder is None and ckpt_sd is not None:
+            # a real checkpoint carries its text encoder (cond_stage_model.*): use it, as the reference does
+            text_encoder = "clip" if udesc.context_dim == 768 else "bert"
+        strict_tok = ckpt_sd is not None or not synthetic_allowed()
         if cond_stage is None and text_encoder == "clip":
             # `[gan] text_encoder = clip`: FrozenCLIPEmbedder on the engine (768-wide contexts: the SD U-Net)
             from .text_encoders import FrozenCLIPEmbedderHIP
             assert udesc.context_dim == 768, "the CLIP ViT-L/14 text encoder conditions the SD-v1 U-Net"
-            cond_stage = FrozenCLIPEmbedderHIP(self.engine, state_dict=ckpt_sd)  # cond_stage_model.transformer.*
+            cond_stage = FrozenCLIPEmbedderHIP(self.engine, state_dict=ckpt_sd,  # cond_stage_model.transformer.*
+                                               require_vocab=strict_tok)
         elif cond_stage is None and text_encoder == "bert":
             # `[gan] text_encoder = bert`: BERTEmbedder of LDM text2img-large (1280-wide contexts)
             from .text_encoders import BERTEmbedderHIP
             assert udesc.context_dim == 1280, "the BERT / x-transformer encoder conditions the LDM text2img U-Net"
-            cond_stage = BERTEmbedderHIP(self.engine, state_dict=ckpt_sd)
-        self.cond_stage = cond_stage or StandInTextEmbedder(udesc.context_dim)
+            cond_stage = BERTEmbedderHIP(self.engine, state_dict=ckpt_sd, require_vocab=strict_tok)
+        if cond_stage is None:
+            if not synthetic_allowed():
+                raise RuntimeError("no text encoder: pass cond_stage / text_encoder, or load a checkpoint that has one")
+            cond_stage = StandInTextEmbedder(udesc.context_dim)
+        self.cond_stage = cond_stage
         if ranker == "directional_clip":  # `[gan] ranker = directional_clip`: the reference's DirectionalCLIP on the engine
             from .ranker import DirectionalCLIPHIP
-            ranker = DirectionalCLIPHIP(self.engine)
+            rpath = ranker_path or os.environ.get("CYCLEDIFF_CLIP_RANKER")
+            rsd = None
+            if rpath:
+                rsd = torch.load(rpath, map_location="cpu")
+                rsd = rsd.get("state_dict", rsd) if isinstance(rsd, dict) else rsd.state_dict()
+            elif not synthetic_allowed():
+                raise FileNotFoundError("ranker = directional_clip needs the CLIP ViT-B/32 state_dict: set `ranker_path` "
+                                        "or CYCLEDIFF_CLIP_RANKER (or CYCLEDIFF_SYNTHETIC_WEIGHTS=1 for random towers)")
+            ranker = DirectionalCLIPHIP(self.engine, state_dict=rsd, require_vocab=rsd is not None)
         self.ranker = ranker
         self.alphas_cumprod = schedule.latent_alphas_cumprod(1000, self.LINEAR_START, self.LINEAR_END)
         # `next(self.parameters()).device` must work (sd_wrapper:251-253) and DDP must be able to wrap us

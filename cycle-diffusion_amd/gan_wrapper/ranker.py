@@ -37,8 +37,11 @@ def clip_preprocess(img, res=224):
 class _ClipTokenize:
     """clip.tokenize framing: [sot] tokens [eot], zero padded to the context length."""
 
-    def __init__(self, context_length=77):
+    def __init__(self, context_length=77, require_vocab=False):
         vocab_dir = os.environ.get("CYCLEDIFF_CLIP_TOKENIZER", "")
+        if require_vocab and not vocab_dir:
+            raise FileNotFoundError("CLIP BPE vocabulary missing: point CYCLEDIFF_CLIP_TOKENIZER at a directory with "
+                                    "vocab.json + merges.txt (real CLIP weights need the real tokenizer)")
         self.inner = ClipBpeTokenizer(vocab_dir, context_length) if vocab_dir else HashTokenizer(context_length)
         self.context_length = context_length
 
@@ -52,7 +55,7 @@ class _ClipTokenize:
 
 
 class DirectionalCLIPHIP:
-    def __init__(self, engine, state_dict=None, seed=9):
+    def __init__(self, engine, state_dict=None, seed=9, require_vocab=False):
         self.engine = engine
         self.text = engine.create_net(oclip_text_desc())
         self.vision = engine.create_net(oclip_vision_desc())
@@ -66,7 +69,7 @@ class DirectionalCLIPHIP:
             engine.random_init(self.text, seed=seed)
             engine.random_init(self.vision, seed=seed + 1)
             self.weights_origin = "synthetic(seed=%d)" % seed
-        self.tokenize = _ClipTokenize()
+        self.tokenize = _ClipTokenize(require_vocab=require_vocab)
 
     def features(self, img=None, text=None):
         if img is not None:

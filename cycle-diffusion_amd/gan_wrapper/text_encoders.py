@@ -55,7 +55,7 @@ class ClipBpeTokenizer:
 class FrozenCLIPEmbedderHIP:
     CKPT_PREFIX = "cond_stage_model.transformer."
 
-    def __init__(self, engine, state_dict=None, seed=7, max_length=77):
+    def __init__(self, engine, state_dict=None, seed=7, max_length=77, require_vocab=False):
         self.engine = engine
         self.net = engine.create_net(clip_text_desc(positions=max_length))
         if state_dict is not None:
@@ -67,6 +67,9 @@ class FrozenCLIPEmbedderHIP:
             engine.random_init(self.net, seed=seed)
             self.weights_origin = "synthetic(seed=%d)" % seed
         vocab_dir = os.environ.get("CYCLEDIFF_CLIP_TOKENIZER", "")
+        if require_vocab and not vocab_dir:
+            raise FileNotFoundError("CLIP BPE vocabulary missing: point CYCLEDIFF_CLIP_TOKENIZER at a directory with "
+                                    "vocab.json + merges.txt (real text-encoder weights need the real tokenizer)")
         self.tokenizer = ClipBpeTokenizer(vocab_dir, max_length) if vocab_dir else HashTokenizer(max_length)
 
     def __call__(self, texts):
@@ -111,7 +114,7 @@ class BERTEmbedderHIP:
     tokenizer ids -> x-transformers encoder on the engine -> [B, 77, 1280]."""
     CKPT_PREFIX = "cond_stage_model.transformer."
 
-    def __init__(self, engine, state_dict=None, seed=8, max_length=77, width=1280, layers=32):
+    def __init__(self, engine, state_dict=None, seed=8, max_length=77, width=1280, layers=32, require_vocab=False):
         self.engine = engine
         self.net = engine.create_net(bert_xtransformer_desc(width=width, layers=layers, positions=max_length))
         if state_dict is not None:
@@ -123,6 +126,9 @@ class BERTEmbedderHIP:
             engine.random_init(self.net, seed=seed)
             self.weights_origin = "synthetic(seed=%d)" % seed
         vocab_dir = os.environ.get("CYCLEDIFF_BERT_TOKENIZER", "")
+        if require_vocab and not vocab_dir:
+            raise FileNotFoundError("BERT WordPiece vocabulary missing: point CYCLEDIFF_BERT_TOKENIZER at a directory "
+                                    "with vocab.txt (real text-encoder weights need the real tokenizer)")
         self.tokenizer = BertWordPieceTokenizer(vocab_dir, max_length) if vocab_dir else BertHashTokenizer(max_length)
 
     def __call__(self, texts):

@@ -8,34 +8,68 @@ import torch.distributed as dist
 
 
 def shard_range(n_items, world_size, rank):
-    """Contiguous slice of a global batch for `rank` (global chunks of B_local*world split contiguously)."""
+    """Contiguous slice of ONE global batch for `rank` when the batch divides evenly (bench.py: global batch =
+    B_local * world). For a whole dataset use shard_indices (ShardSampler semantics incl. wrap-around padding)."""
     per = (n_items + world_size - 1) // world_size
     lo = min(n_items, rank * per)
     return lo, min(n_items, lo + per)
 
 
-def _concat(t):
+def shard_indices(n_items, batch_size, world_size, rank):
+    """HF `ShardSampler(dataset, batch_size, num_processes, process_index)` as the reference's eval loader uses it
+    (trainer/trainer.py:288-293): the index list is padded by WRAP-AROUND to a multiple of batch_size * world_size,
+    cut in global batches of that size, and each global batch is split contiguously - rank r takes
+    [r * batch_size, (r + 1) * batch_size). Every rank therefore gets the same number of full batches (collectives
+    never see ragged shapes); the padding is dropped after the gather by gather_outputs(..., num_total_examples).
+    Returns the list of per-step index lists for `rank`."""
+    if n_items <= 0:
+        return []
+    gb = batch_size * world_size
+    total = ((n_items + gb - 1) // gb) * gb
+    idx = list(range(n_items))
+    while len(idx) < total:
+        idx += idx[: total - len(idx)]
+    return [idx[g0 + rank * batch_size: g0 + (rank + 1) * batch_size] for g0 in range(0, total, gb)]
+
+
+def global_order(n_items, batch_size, world_size):
+    """dataset index of every row of the concatenated per-step gathers (step-major, then rank-major), padding
+    included - what distributed_concat + nested_concat produce in the reference's eval loop (trainer.py:825-840)."""
+    steps = [shard_indices(n_items, batch_size, world_size, r) for r in range(world_size)]
+    out = []
+    for s in range(len(steps[0]) if steps else 0):
+        for r in range(world_size):
+            out += steps[r][s]
+    return out
+
+
+def _concat(t, num_total_examples=None):
+    """distributed_concat on one leaf (trainer/trainer.py:43-61): all_gather in rank order, 0-d tensors become 1-d,
+    optional truncation of the sampler's padding."""
+    if t is None:
+        return None
     if not (dist.is_available() and dist.is_initialized()):
-        return t
-    t = t.contiguous()
-    outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
-    dist.all_gather(outs, t)
-    return torch.cat(outs, dim=0)
-
-
-def gather_outputs(tensors, loss=None):
-    """nested tuple of per-rank tensors -> same structure concatenated along dim 0 in rank order."""
-    if isinstance(tensors, (tuple, list)):
-        out = type(tensors)(_gather_nested(t) for t in tensors)
+        out = t if t.dim() > 0 else t[None]
     else:
-        out = _concat(tensors)
-    return out, (_concat(loss) if loss is not None else None)
+        t = t.contiguous()
+        outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(outs, t)  # same shape on every rank: shard_indices pads the last global batch
+        out = torch.cat([o if o.dim() > 0 else o[None] for o in outs], dim=0)
+    return out[:num_total_examples] if num_total_examples is not None else out
 
 
-def _gather_nested(t):
+def _gather_nested(t, num_total_examples=None):
     if isinstance(t, (tuple, list)):
-        return type(t)(_gather_nested(x) for x in t)
-    return _concat(t)
+        return type(t)(_gather_nested(x, num_total_examples) for x in t)
+    if isinstance(t, dict):
+        return type(t)({k: _gather_nested(v, num_total_examples) for k, v in t.items()})
+    return _concat(t, num_total_examples)
+
+
+def gather_outputs(tensors, loss=None, num_total_examples=None):
+    """nested tuple / list / dict of per-rank tensors (None leaves pass through) -> same structure concatenated along
+    dim 0 in rank order; `num_total_examples` truncates the wrap-around padding of the last global batch."""
+    return _gather_nested(tensors, num_total_examples), _concat(loss, num_total_examples)
 
 
 def run_in_flight(n_steps, n_replicas, compute, finish):

@@ -36,11 +36,16 @@ def read_checkpoint(ckpt_path):
     return sd
 
 
+def synthetic_allowed():
+    return os.environ.get("CYCLEDIFF_SYNTHETIC_WEIGHTS", "0") == "1"
+
+
 def load_or_init_weights(engine, ckpt_path, nets_and_prefixes, seed=0, state_dict=None):
     """Load a reference checkpoint by its state_dict names (txt2img.py:25-42: pl_sd["state_dict"];
-    ddpm_ddim_wrapper.py:378-379: plain dict). There are no checkpoints in this tree (ckpts/ is empty,
-    SURVEY.md §0): unless CYCLEDIFF_SYNTHETIC_WEIGHTS=0, missing files fall back to seeded synthetic
-    weights (identical on every rank) so configs still run end to end."""
+    ddpm_ddim_wrapper.py:378-379: plain dict). A missing checkpoint is an error, as in the reference (torch.load
+    raises). Seeded synthetic weights (identical on every rank) are OPT-IN: CYCLEDIFF_SYNTHETIC_WEIGHTS=1, which
+    bench.py, the tests and `main.py --synthetic-weights` set - there are no checkpoints in this tree.
+    Returns the origin string recorded in metrics.json."""
     sd = state_dict if state_dict is not None else read_checkpoint(ckpt_path)
     if sd is not None:
         for net, prefix in nets_and_prefixes.items():
@@ -48,9 +53,10 @@ def load_or_init_weights(engine, ckpt_path, nets_and_prefixes, seed=0, state_dic
             if n:
                 raise KeyError("checkpoint %s lacks %d tensors, first: %s" % (ckpt_path, n, first))
         return ckpt_path
-    if os.environ.get("CYCLEDIFF_SYNTHETIC_WEIGHTS", "1") == "0":
-        raise FileNotFoundError(ckpt_path)
-    warnings.warn("checkpoint %s not found: using seeded synthetic weights" % ckpt_path)
+    if not synthetic_allowed():
+        raise FileNotFoundError("checkpoint %s not found (set CYCLEDIFF_SYNTHETIC_WEIGHTS=1 to run on seeded synthetic "
+                                "weights instead)" % ckpt_path)
+    warnings.warn("checkpoint %s not found: using seeded synthetic weights (CYCLEDIFF_SYNTHETIC_WEIGHTS=1)" % ckpt_path)
     share = os.environ.get("CYCLEDIFF_SHARE_SYNTH", "0") == "1"  # bench.py: several replicas, same seeds
     for i, net in enumerate(nets_and_prefixes):
         engine.random_init(net, seed=seed + i, cache=share)

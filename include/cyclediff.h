@@ -30,6 +30,7 @@ typedef struct cd_engine* cd_handle;
 enum { CD_NET_UNET_OPENAI = 1, CD_NET_UNET_HO = 2, CD_NET_VAE_KL = 3, CD_NET_CLIP_TEXT = 4, CD_NET_BERT_XTR = 5,
        CD_NET_OCLIP_TEXT = 6, CD_NET_OCLIP_VISION = 7 };
 enum { CD_SCHED_DDIM = 0, CD_SCHED_DDPM = 1 };
+enum { CD_PREC_16 = 0, CD_PREC_F32 = 1 };
 
 /* Architecture descriptor (the hyper-parameters of the reference's YAML / dict configs):
  *   UNET_OPENAI : ldm/modules/diffusionmodules/openaimodel.py:413-470 (SD v1, LDM text2img) and
@@ -62,7 +63,12 @@ typedef struct cd_net_desc {
   int use_scale_shift_norm, resblock_updown, conv_resample;
   /* VAE */
   int z_channels, embed_dim, double_z;
-  int reserved[8];
+  /* Storage / arithmetic of the network: CD_PREC_16 = 16-bit activations and weights, fp32 accumulate (default);
+   * CD_PREC_F32 = fp32 activations, weights and matrix instructions - what the reference itself computes in
+   * (`use_fp16=False`, improved_ddpm/script_util.py:15). U-Nets without SpatialTransformer blocks only: the
+   * pixel-space DDPMs of ddpm_ddim_wrapper.py, whose 'ddim' chain needs eps_hat at fp32 resolution. */
+  int precision;
+  int reserved[7];
 } cd_net_desc;
 
 /* Per-step scheduler coefficients, evaluated by the host in fp32 in the reference's operation

@@ -2,7 +2,7 @@
 
 A compact stand-in for the reference's `main.py --do_eval` (HF Trainer harness, main.py:57-160,
 trainer/trainer.py:793-900): same experiment configs (`--cfg experiments/*.cfg`), same model API, same per-rank
-sharding (contiguous slices, ShardSampler) and the same per-image metrics (evaluation/translate_text.py: PSNR, SSIM,
+sharding (HF ShardSampler: global batches of B * world split contiguously, last one padded by wrap-around) and the same per-image metrics (evaluation/translate_text.py: PSNR, SSIM,
 L2 against the input; CLIP / directional CLIP when the config selects `ranker = directional_clip`).
 
   python main.py --cfg experiments/toy_ddpm_c1.cfg --data triplets.json --output_dir out [--per_device_eval_batch_size 4]
@@ -28,7 +28,12 @@ def main(argv=None):
     ap.add_argument("--per_device_eval_batch_size", type=int, default=4)
     ap.add_argument("--range", type=int, nargs=2, default=None, metavar=("START", "END"))
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--synthetic-weights", action="store_true",
+                    help="run on seeded synthetic weights when a checkpoint file is missing (default: error, as the "
+                         "reference's torch.load); recorded as weights_origin in metrics.json")
     a = ap.parse_args(argv)
+    if a.synthetic_weights:
+        os.environ["CYCLEDIFF_SYNTHETIC_WEIGHTS"] = "1"
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -39,7 +44,7 @@ def main(argv=None):
 
     import cycle_diffusion_amd  # noqa: F401
     from cycle_diffusion_amd.data.triplets import TripletDataset, collate
-    from cycle_diffusion_amd.parallel import shard_range
+    from cycle_diffusion_amd.parallel import shard_indices
     from cycle_diffusion_amd.utils import metrics
     from cycle_diffusion_amd.utils.config_utils import get_config
     from cycle_diffusion_amd.utils.program_utils import get_model
@@ -50,12 +55,11 @@ def main(argv=None):
     wrapper = getattr(model, "gan_wrapper", None) or model.source_gan_wrapper
     start, end = a.range if a.range else (0, None)
     ds = TripletDataset(a.data, wrapper.resolution, start, end)
-    lo, hi = shard_range(len(ds), world, rank)
     os.makedirs(a.output_dir, exist_ok=True)
     dev = torch.device("cuda", local)
     rows = []
-    for b0 in range(lo, hi, a.per_device_eval_batch_size):
-        batch = collate([ds[i] for i in range(b0, min(hi, b0 + a.per_device_eval_batch_size))])
+    for step_idx in shard_indices(len(ds), a.per_device_eval_batch_size, world, rank):
+        batch = collate([ds[i] for i in step_idx])
         kw = {"sample_id": batch["sample_id"].to(dev), "original_image": batch["original_image"].to(dev)}
         if "encode_text" in batch:
             kw.update(encode_text=batch["encode_text"], decode_text=batch["decode_text"])
@@ -81,10 +85,12 @@ def main(argv=None):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        rows = list({r["sample_id"]: r for r in rows}.values())  # the sampler's wrap-around padding repeats samples
         rows.sort(key=lambda r: r["sample_id"])
         summary = {k: sum(r[k] for r in rows) / max(1, len(rows)) for k in ("psnr", "ssim", "l2")}
         with open(os.path.join(a.output_dir, "metrics.json"), "w") as fh:
-            json.dump({"summary": summary, "samples": rows}, fh, indent=1)
+            json.dump({"summary": summary, "weights_origin": getattr(wrapper, "weights_origin", None),
+                       "samples": rows}, fh, indent=1)
         print(json.dumps({"n": len(rows), **summary}))
     return 0
 

@@ -217,6 +217,36 @@ def gen_c1():
              z_norms=z25.flatten(2).norm(dim=2), img=out2)
 
 
+def _pixel_chain(name, net, wseed, custom_steps, es_steps, refine_steps, img_seed, seeds):
+    """DDPMDDIMWrapper.encode -> forward without refinement -> forward with refinement (fresh seed each), 'ddim'
+    eta 0.1 (ddpm_ddim_wrapper.py:455-534, 392-453)."""
+    with torch.no_grad():
+        ns, _ = load_synth(net, wseed)
+        w = build_ref_pixel_wrapper(net, custom_steps=custom_steps, es_steps=es_steps, eta=0.1, refine_steps=0)
+        img = torch.rand((1, 3, 32, 32), generator=torch.Generator().manual_seed(img_seed))
+        torch.manual_seed(seeds[0])
+        with ref_import.quiet():
+            z = w.encode(image=img)
+            out0 = w(z=z)
+        w.refine_steps = refine_steps
+        torch.manual_seed(seeds[1])
+        with ref_import.quiet():
+            out1 = w(z=z)
+        z5 = z.view(1, es_steps, 3, 32, 32)
+        slots = [0, 1, es_steps // 2, es_steps - 1]
+        save(name, names=json.dumps(ns), wseed=wseed, noise_seed=seeds[0], refine_seed=seeds[1], img_seed=img_seed,
+             custom_steps=custom_steps, es_steps=es_steps, refine_steps=refine_steps, z_sub=z5[:, slots],
+             z_sub_slots=np.asarray(slots), z_norms=z5.flatten(2).norm(dim=2), img=out0, img_refined=out1)
+
+
+def gen_pixel_refine():
+    """a11 / C5: the refinement loop (refine_steps > 0) on the C1 toy network, and a reduced C5-shaped chain
+    (custom_steps 100, es_steps 85, refine_steps 10 = the reference cfg's 1000 / 850 / 100 divided by 10) on the
+    improved-DDPM architecture (6 output channels of which 3 are dropped, ddpm_ddim_wrapper.py:237-238)."""
+    _pixel_chain("c1_toy_ddpm_refine", build_ref_ho(), 106, 50, 50, 10, 11, (4321, 777))
+    _pixel_chain("c5_tiny_iddpm_chain", build_ref_iddpm(), 107, 100, 85, 10, 12, (2468, 1357))
+
+
 def gen_xtr_text():
     """LDM text encoder: the reference's vendored x-transformers TransformerWrapper on seeded weights / ids."""
     ref_import.setup()
@@ -239,7 +269,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    todo = dict(schedule=gen_schedule, nets=gen_nets, latent=gen_latent_cycle, c1=gen_c1, xtr=gen_xtr_text)
+    todo = dict(schedule=gen_schedule, nets=gen_nets, latent=gen_latent_cycle, c1=gen_c1, xtr=gen_xtr_text,
+                pixel_refine=gen_pixel_refine)
     for k, fn in todo.items():
         if not a.only or a.only == k:
             fn()

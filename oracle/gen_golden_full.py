@@ -1,0 +1,97 @@
+"""Full-size end-to-end fixtures from the REFERENCE's own modules (CPU fp32, imported from /root/reference).
+
+  python -m oracle.gen_golden_full --only c2      (~25 min on 8 cores)
+  python -m oracle.gen_golden_full --only c3      (~6 min)
+
+One (image, source-text, target-text) triplet per BASELINE configuration, run the way the reference's
+text wrapper composes it (stable_diffusion_stochastic_text_wrapper.py:169-249): VAE encode -> posterior
+sample (SD, ddpm.py:538) / mean (LDM, latentdiff ddpm.py:535-538) x 0.18215 -> DDIMSampler.ddpm_ddim_encoding
+(99 steps, eta 0.1, encoder scale 1; ddim.py:230-286,450-501) -> DDIMSampler.sample_with_eps towards the
+target text with classifier-free guidance 3 (ddim.py:170-228,395-448) -> VAE decode -> (x + 1) / 2.
+
+Weights: oracle.nets.synth_state_dict over the reference modules' own (name, shape) lists (stored in the
+fixture so the GPU box rebuilds them without the reference); inputs and contexts from torch.Generator seeds;
+every noise draw comes from the global generator after torch.manual_seed(noise_seed), in the reference's
+own draw order (posterior sample first, then randn_like(x0), then one randn per sample_xt_next).
+TEST INFRASTRUCTURE ONLY.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_import  # noqa: E402
+from oracle.gen_golden import RefVAE, build_ref_sd_unet, load_synth, rnd, save  # noqa: E402
+
+FULL_VAE = dict(ch=128, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=[], in_channels=3,
+                resolution=256, z_channels=4, double_z=True, dropout=0.0)
+SD_UNET = dict(image_size=32, in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1],
+               num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
+               transformer_depth=1, context_dim=768, use_checkpoint=False, legacy=False)  # v1-inference.yaml:29-44
+LDM_UNET = dict(SD_UNET, context_dim=1280)  # txt2img-1p4B-eval.yaml
+
+SEEDS = dict(unet=0, vae=1, image=1, c_src=2, uc=3, c_tgt=5, noise=4)
+
+
+def run_text_triplet(name, unet_cfg, res, ctx_dim, sample_posterior, steps=99, eta=0.1, dec_scale=3.0):
+    ref_import.setup()
+    from ldm.modules.distributions.distributions import DiagonalGaussianDistribution
+    Sampler = ref_import.ddim_sampler_cls()
+    t0 = time.time()
+    with torch.no_grad():
+        u = build_ref_sd_unet(unet_cfg)
+        uns, _ = load_synth(u, SEEDS["unet"])
+        v = RefVAE(FULL_VAE)
+        vns, _ = load_synth(v, SEEDS["vae"])
+        shim = ref_import.LatentShim(u)
+        lat = res // 8
+        image = torch.rand((1, 3, res, res), generator=torch.Generator().manual_seed(SEEDS["image"]))
+        c_src, uc, c_tgt = (rnd((1, 77, ctx_dim), SEEDS[k]) for k in ("c_src", "uc", "c_tgt"))
+        torch.manual_seed(SEEDS["noise"])
+        # encode_first_stage + get_first_stage_encoding (ddpm.py:536-543)
+        post = DiagonalGaussianDistribution(v.moments((image - 0.5) * 2.0))
+        x0 = (post.sample() if sample_posterior else post.mode()) * 0.18215
+        print(name, "vae encode done", time.time() - t0, flush=True)
+        with ref_import.quiet():
+            z_list = Sampler(shim).ddpm_ddim_encoding(steps, batch_size=1, shape=(4, lat, lat), conditioning=c_src,
+                                                      eta=eta, white_box_steps=steps + 1, skip_steps=0, verbose=False,
+                                                      x0=x0, unconditional_guidance_scale=1,
+                                                      unconditional_conditioning=uc)
+        z = torch.stack(z_list, dim=1)
+        print(name, "encode done", time.time() - t0, flush=True)
+        with ref_import.quiet():
+            x_tgt, _ = Sampler(shim).sample_with_eps(steps, z[:, 1:], conditioning=c_tgt, batch_size=1,
+                                                     shape=(4, lat, lat), eta=eta, verbose=False, x_T=z[:, 0],
+                                                     skip_steps=0, unconditional_guidance_scale=dec_scale,
+                                                     unconditional_conditioning=uc)
+        print(name, "decode done", time.time() - t0, flush=True)
+        img = (v.decode(x_tgt / 0.18215) + 1.0) / 2.0  # decode_first_stage (ddpm.py:705) + post_process
+    save(name, unet_names=json.dumps(uns), vae_names=json.dumps(vns), seeds=json.dumps(SEEDS), steps=steps, eta=eta,
+         dec_scale=dec_scale, sample_posterior=int(sample_posterior), x0=x0,
+         z_sub=z[:, [0, 1, 50, 99]], z_sub_slots=np.asarray([0, 1, 50, 99]), z_norms=z.flatten(2).norm(dim=2),
+         x_tgt=x_tgt, img=img, cpu_seconds=time.time() - t0, cpu_threads=torch.get_num_threads())
+
+
+def gen_c2():
+    """BASELINE config 2 (headline): Stable-Diffusion-v1.4 shapes, 512 x 512."""
+    run_text_triplet("c2_sd512_e2e", SD_UNET, 512, 768, sample_posterior=True)
+
+
+def gen_c3():
+    """BASELINE config 3: LDM text2img-large shapes, 256 x 256 (posterior mean)."""
+    run_text_triplet("c3_ldm256_e2e", LDM_UNET, 256, 1280, sample_posterior=False)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    for k, fn in dict(c3=gen_c3, c2=gen_c2).items():
+        if not a.only or a.only == k:
+            fn()

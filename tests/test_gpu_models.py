@@ -1,9 +1,10 @@
 """Network- and sampler-level parity on the GPU: the HIP engine (through the C ABI) against the CPU
 oracle and against the committed reference fixtures, on identical weights / inputs / noise.
 
-Tolerance model: the engine stores activations in bf16 (8-bit mantissa) and accumulates in fp32, so
-a network output differs from the fp32 reference by a few 1e-3 of its scale; bounds below are
-REL (max|err|/max|ref|) and PSNR in image space (evaluation/utils.py:60-67 convention)."""
+Tolerance model: the 16-bit engine stores activations in fp16 (10-bit mantissa; bf16 is a build switch) and
+accumulates in fp32, so a network output differs from the fp32 reference by a few 1e-3 of its scale; the fp32 path
+(CD_PREC_F32, pixel-space DDPMs) differs by fp32 round-off only. Bounds below are REL (max|err|/max|ref|) and PSNR
+in image space (evaluation/utils.py:60-67 convention)."""
 import numpy as np
 import pytest
 import torch
@@ -131,9 +132,11 @@ def test_latent_cycle_tiny(engine, report):
     _check(report, "sampler/latent_x_tgt", x_tgt, fx["x_tgt"], rel=3e-2 * FMT, mean=1.5e-2 * FMT)  # measured 6e-3 / 3e-3
 
 
-def _c1(engine, report, fx_name, steps, eta, sample_type):
+def _c1(engine, report, fx_name, steps, eta, sample_type, precision=_ffi.CD_PREC_16):
     fx = gu.load(fx_name)
-    net, sd = _load(engine, cda.ho_ddpm_desc(32, 32, (1, 2, 2), 1, (16,)), fx)
+    net, sd = _load(engine, cda.ho_ddpm_desc(32, 32, (1, 2, 2), 1, (16,), precision=precision), fx)
+    f32 = precision == _ffi.CD_PREC_F32
+    tag = fx_name + ("_f32" if f32 else "")
     img = torch.rand((1, 3, 32, 32), generator=torch.Generator().manual_seed(11))
     x0 = (img - 0.5) * 2.0
     enc_noise, last = gu.pixel_noise(int(fx["noise_seed"]), x0.shape, steps)
@@ -147,19 +150,31 @@ def _c1(engine, report, fx_name, steps, eta, sample_type):
     zs = z.cpu()[:, [1, steps // 2, steps - 1]]
     zr = torch.as_tensor(fx["z_sub"][:, 1:])
     zerr = ((zs - zr).flatten(2).abs().max(dim=2).values / zr.flatten(2).abs().max(dim=2).values)[0]
-    report.add("sampler/" + fx_name + "_z", rel_first=float(zerr[0]), rel_mid=float(zerr[1]), rel_last=float(zerr[2]))
-    assert zerr[0] < 6e-3 * FMT and zerr[1] < 6e-3 * FMT and zerr[2] < 2e-2 * FMT, zerr  # measured ~1e-3
+    report.add("sampler/" + tag + "_z", rel_first=float(zerr[0]), rel_mid=float(zerr[1]), rel_last=float(zerr[2]))
+    if f32:  # fp32 round-off, amplified by the chain towards the last slots
+        assert zerr[0] < 1e-4 and zerr[1] < 1e-3 and zerr[2] < 1e-2, zerr
+    else:
+        assert zerr[0] < 6e-3 * FMT and zerr[1] < 6e-3 * FMT and zerr[2] < 2e-2 * FMT, zerr  # measured ~1e-3
     x = engine.ddim_decode(net, sch.kind, z, sch.coef_decode(), n_eps=steps - 1, noise_tail=last[None].cuda())
     out = (x.cpu() + 1.0) / 2.0
     p_ref = gu.psnr(out, torch.as_tensor(fx["img"]))
     p_img = gu.psnr(out, img)
-    report.add("sampler/" + fx_name, psnr_vs_reference=p_ref, psnr_vs_input=p_img,
+    report.add("sampler/" + tag, psnr_vs_reference=p_ref, psnr_vs_input=p_img,
                ref_psnr_vs_input=gu.psnr(torch.as_tensor(fx["img"]), img))
     return p_ref, p_img
 
 
-def test_c1_toy_ddpm_ddim_eta(engine, report):
-    """BASELINE config 1 on the engine vs the reference's CPU run (fixture)."""
+def test_c1_toy_ddpm_ddim_eta_fp32(engine, report):
+    """BASELINE config 1 ('ddim', eta 0.1, 50 + 50 steps) on the engine's fp32 path vs the reference's CPU run:
+    image PSNR >= 40 dB against the reference image (whose own PSNR against the input is 48 dB), and the result is
+    bit-identical from run to run (fixed tiles, fixed accumulation order)."""
+    p_ref, p_img = _c1(engine, report, "c1_toy_ddpm", 50, 0.1, "ddim", precision=_ffi.CD_PREC_F32)
+    assert p_ref >= 40.0, p_ref
+    assert p_img >= 40.0, p_img
+
+
+def test_c1_toy_ddpm_ddim_eta_16bit(engine, report):
+    """The same chain on the 16-bit engine: reported, and held only to a liveness floor (see the comment)."""
     p_ref, p_img = _c1(engine, report, "c1_toy_ddpm", 50, 0.1, "ddim")
     # The 'ddim' chain of the DDPM linear schedule rescales x by sqrt(abar_{t-1}/abar_t) every step
     # (x130 end to end) and, on a RANDOM-INIT network, nothing damps it: the fp32 reference closes the

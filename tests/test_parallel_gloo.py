@@ -34,6 +34,67 @@ def _worker(rank, world, port, n_items, q):
     dist.destroy_process_group()
 
 
+def _worker_ragged(rank, world, port, n_items, bsz, q):
+    """n_items % (bsz * world) != 0: every rank still runs the same number of full batches (wrap-around padding),
+    the gathers never see ragged shapes, and truncation to num_total_examples restores the dataset."""
+    from cycle_diffusion_amd.parallel import global_order, shard_indices
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = torch.arange(n_items * 3, dtype=torch.float32).view(n_items, 3)
+    steps = shard_indices(n_items, bsz, world, rank)
+    rows, ids = [], []
+    for idx in steps:
+        assert len(idx) == bsz
+        local = full[idx]
+        (img, none_leaf, d), sid = gather_outputs((local * 2, None, {"k": local + 1}), torch.tensor(idx))
+        assert none_leaf is None and img.shape[0] == bsz * world and torch.equal(d["k"], img / 2 + 1)
+        rows.append(img)
+        ids.append(sid)
+    rows, ids = torch.cat(rows), torch.cat(ids)
+    order = global_order(n_items, bsz, world)
+    ok = ids.tolist() == order and torch.equal(rows, full[order] * 2)
+    # a scalar leaf becomes 1-d, and truncation drops the padding of a single gather
+    (sc,), _ = gather_outputs((torch.tensor(float(rank)),), None, num_total_examples=world - 1 if world > 1 else 1)
+    ok = ok and sc.tolist() == [float(r) for r in range(max(1, world - 1))]
+    # dataset order is recovered by sample id (what main.py does)
+    seen = {}
+    for i, r in zip(ids.tolist(), rows):
+        seen[i] = r
+    ok = ok and sorted(seen) == list(range(n_items)) and all(torch.equal(seen[i], full[i] * 2) for i in seen)
+    q.put((rank, bool(ok), len(steps)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_sampler_semantics_single_process():
+    from cycle_diffusion_amd.parallel import global_order, shard_indices
+    # HF ShardSampler docstring example: 2 processes, batch 4, 16 items
+    assert shard_indices(16, 4, 2, 0) == [[0, 1, 2, 3], [8, 9, 10, 11]]
+    assert shard_indices(16, 4, 2, 1) == [[4, 5, 6, 7], [12, 13, 14, 15]]
+    # 10 items: padded by wrap-around to 16
+    assert shard_indices(10, 4, 2, 0) == [[0, 1, 2, 3], [8, 9, 0, 1]]
+    assert shard_indices(10, 4, 2, 1) == [[4, 5, 6, 7], [2, 3, 4, 5]]
+    assert global_order(10, 4, 2)[:10] == list(range(10))
+    assert shard_indices(0, 4, 2, 0) == [] and shard_indices(3, 4, 1, 0) == [[0, 1, 2, 0]]
+
+
+def test_ragged_dataset_gather_world2():
+    world, n_items, bsz = 2, 10, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ragged, args=(r, world, port, n_items, bsz, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert all(n == 2 for _, _, n in res)
+
+
 def test_shard_ranges_partition_the_batch():
     for n, w in ((8, 2), (64, 8), (32, 8), (4, 1)):
         spans = [shard_range(n, w, r) for r in range(w)]
