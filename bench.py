@@ -10,6 +10,15 @@ A "step" = one pass of the hot path over one batch of 4 image triplets per GPU: 
 forward = wrapper.encode (VAE encode + DPM-Encoder) + wrapper.forward (coupled decode + VAE decode),
 i.e. exactly what Trainer.prediction_step times in the reference (trainer/trainer.py:788-789), followed
 by the per-step output gather (trainer.py:833). Prints ONE JSON line on rank 0.
+
+Steps are issued `--coalesce` at a time (default 4): the engine folds the queued batches into ONE launch set
+(16 images through the DPM-Encoder, 32 rows through the CFG decode), so every GEMM sees 4x the rows with one copy
+of the weights; each step still gets its own all-gather, in step order. `--in-flight R` additionally keeps R
+such launch sets running on R independent engines / HIP streams.
+
+Other BASELINE.json configurations: `--workload c3` (LDM text2img-large shapes, 256 x 256, batch 16) and
+`--workload c5r` (AFHQ improved-DDPM pair, 256 x 256, batch 4; REDUCED chain custom_steps 100 / es_steps 85 /
+refine_steps 10 = the reference cfg's 1000 / 850 / 100 divided by 10 - labelled as such in the line).
 """
 import argparse
 import json
@@ -27,6 +36,24 @@ F_UNET, F_VAE_ENC, F_VAE_DEC = 803.3e9, 1116.7e9, 2514.5e9   # FLOPs / sample (B
 N_STEPS = 99
 F_IMG = F_VAE_ENC + N_STEPS * F_UNET + N_STEPS * 2 * F_UNET + F_VAE_DEC   # 242.2 TFLOP / image
 PEAK_TFLOPS = 2500.0  # dense 16-bit MFMA peak (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3  # fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
+
+WORKLOADS = {
+    "c2": dict(cfg="experiments/bench_sd_c2.cfg", res=512, batch=4, text=True, flop_per_image=F_IMG,
+               metric="images/sec, SD-v1.4 512px CycleDiffusion 100+100 steps, 1/2/4/8 MI355X",
+               name="C2: Stable-Diffusion-v1.4-shaped U-Net + KL-f8 VAE, 512x512, custom_steps=99 "
+                    "white_box_steps=100 eta=0.1 skip 0, 1 trial, encoder scale 1, decoder CFG 3"),
+    "c3": dict(cfg="experiments/bench_ldm_c3.cfg", res=256, batch=16, text=True,
+               flop_per_image=272.7e9 + 99 * 182.1e9 + 99 * 2 * 182.1e9 + 622.2e9,   # 55.0 TFLOP
+               metric="images/sec, LDM text2img-large 256px CycleDiffusion 100+100 steps (BASELINE config 3)",
+               name="C3: LDM text2img-large-shaped U-Net (context 1280) + KL-f8 VAE, 256x256, custom_steps=99 "
+                    "white_box_steps=100 eta=0.1 skip 0, 1 trial, encoder scale 1, decoder CFG 3"),
+    "c5r": dict(cfg="experiments/bench_afhq_c5_reduced.cfg", res=256, batch=4, text=False,
+                flop_per_image=(84 + 85 + 10) * 387.9e9,
+                metric="images/sec, AFHQ cat->dog 256px, two improved-DDPM U-Nets, REDUCED chain (BASELINE config 5 / 10)",
+                name="C5 REDUCED: two AFHQ improved-DDPM U-Nets (source / target), 256x256, sample_type ddim eta 0.1, "
+                     "custom_steps=100 es_steps=85 refine_steps=10 (reference cfg: 1000 / 850 / 100)"),
+}
 
 
 def host_cores():
@@ -43,11 +70,14 @@ def host_cores():
 
 
 def cpu_baseline(eng, un, vn, seed=0):
-    """The CPU oracle (torch fp32 restatement of the reference path, oracle/) timed on this box's host
-    cores on a bounded sample: one SD U-Net forward at batch 1 and one at batch 2 (the CFG pair), one
-    VAE encode and one decode at 512x512; extrapolated linearly to 99 + 99 steps (all steps cost the
-    same)."""
-    from oracle import nets
+    """The CPU oracle (torch fp32 restatement of the reference path, oracle/) timed on this box's host cores on a
+    bounded sample of the C2 workload at batch 1: (i) the SD U-Net forward at batch 1 and at batch 2
+    (the CFG pair), best of 3 each, one VAE encode and one decode at 512x512, extrapolated linearly to 99 + 99 steps;
+    (ii) as the cross-check BASELINE.md asks for, a REAL 5-step DPM-Encoder + 5-step CFG-3 decode loop through
+    oracle.samplers, extrapolated the same way. `value` is (i); (ii) is reported beside it. The reference's own
+    modules cannot travel to the GPU box; their full 99 + 99 run on 8 cores here took 1333 s / image
+    (tests/golden/c2_sd512_e2e.npz: cpu_seconds), i.e. 0.00075 images/s."""
+    from oracle import nets, samplers
     cores = host_cores()
     torch.set_num_threads(cores)
     ucfg = nets.OpenAIUNetCfg(in_channels=4, out_channels=4, model_channels=320, num_res_blocks=2,
@@ -61,27 +91,47 @@ def cpu_baseline(eng, un, vn, seed=0):
         x = torch.randn(2, 4, 64, 64, generator=g)
         ctx = torch.randn(2, 77, 768, generator=g)
         t = torch.tensor([501, 501])
+        def best_of(fn, n=3):
+            ts = []
+            for _ in range(n):
+                t0 = time.time(); fn(); ts.append(time.time() - t0)
+            return min(ts), ts
+
         nets.openai_unet(usd, ucfg, x[:1], t[:1], ctx[:1])  # warm-up (thread pool, allocator)
-        t0 = time.time(); nets.openai_unet(usd, ucfg, x[:1], t[:1], ctx[:1]); t_u1 = time.time() - t0
-        t0 = time.time(); nets.openai_unet(usd, ucfg, x, t, ctx); t_u2 = time.time() - t0
+        t_u1, l1 = best_of(lambda: nets.openai_unet(usd, ucfg, x[:1], t[:1], ctx[:1]))
+        t_u2, l2 = best_of(lambda: nets.openai_unet(usd, ucfg, x, t, ctx))
         img = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
         t0 = time.time(); mom = nets.vae_encode_moments(vsd, vcfg, img); t_e = time.time() - t0
         t0 = time.time(); nets.vae_decode(vsd, vcfg, mom[:, :4]); t_d = time.time() - t0
+        # (ii) a real short loop: 5 encode steps + 5 CFG-3 decode steps of the sampler restatement
+        S = 5
+        unet = lambda xx, tt, cc: nets.openai_unet(usd, ucfg, xx, tt, cc)
+        x0 = mom[:, :4] * 0.18215
+        nz = [torch.randn(x0.shape, generator=g) for _ in range(S)]
+        t0 = time.time()
+        z = samplers.latent_encode(samplers.cfg_model(unet, ctx[:1], ctx[1:], 1.0), x0, S, 0.1, nz, white_box_steps=S + 1)
+        t_enc5 = time.time() - t0
+        t0 = time.time()
+        samplers.latent_decode(samplers.cfg_model(unet, ctx[1:], ctx[:1], 3.0), z[0], torch.stack(z[1:], 1), S, 0.1)
+        t_dec5 = time.time() - t0
     per_img = t_e + N_STEPS * t_u1 + N_STEPS * t_u2 + t_d
+    per_img_loop = t_e + N_STEPS * (t_enc5 + t_dec5) / S + t_d
     return {"value": 1.0 / per_img, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "oracle (torch fp32 CPU): 1 U-Net fwd @B=1 %.2fs + 1 @B=2 %.2fs + VAE enc %.2fs + dec %.2fs at "
-                      "512x512, extrapolated linearly to 99 encode + 99 CFG decode steps (%.0f s/image)"
-                      % (t_u1, t_u2, t_e, t_d, per_img)}
+            "value_from_5plus5_loop": 1.0 / per_img_loop,
+            "sample": "oracle (torch fp32 CPU), batch 1: U-Net fwd @B=1 best of 3 %.2fs (%s) + @B=2 %.2fs (%s) + VAE enc "
+                      "%.2fs + dec %.2fs at 512x512, extrapolated linearly to 99 encode + 99 CFG decode steps (%.0f "
+                      "s/image); cross-check: real 5-step encode %.2fs + 5-step CFG decode %.2fs loop -> %.0f s/image"
+                      % (t_u1, " ".join("%.2f" % v for v in l1), t_u2, " ".join("%.2f" % v for v in l2), t_e, t_d,
+                         per_img, t_enc5, t_dec5, per_img_loop)}
 
 
 def pmc_traffic_per_launch():
     """HBM-side bytes per k_conv_gemm launch from the committed rocprofv3 PMC passes (profiles/README.md):
-    FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over one U-Net forward at B'=4 (encode) and B'=8 (CFG
-    decode); a C2 step launches both forward types equally often. None when the summaries are absent."""
+    FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over the U-Net forwards of one coalesced C2 launch set (B'=16
+    encode, B'=32 CFG decode), which launch equally often. None when the summaries are absent."""
     vals = []
-    for b in (4, 8):
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                            "r1_conv_gemm_traffic_unet_b%d.json" % b)
+    for name in ("r2_conv_gemm_traffic_unet_b16.json", "r2_conv_gemm_traffic_unet_b32.json"):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(path) as fh:
                 vals.append(float(json.load(fh)["bytes_per_launch"]))
@@ -93,16 +143,23 @@ def pmc_traffic_per_launch():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4, help="image triplets per GPU per step (README.md:153)")
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="image triplets per GPU per step (default: the workload's "
+                    "BASELINE batch: 4 for C2, README.md:153; 16 for C3, README.md:195)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=4,
-                    help="batches in flight per GPU: independent engine replicas (own HIP stream, workspace and "
-                         "weights) driven by host threads; every step is still one batch of --batch triplets")
+    ap.add_argument("--coalesce", type=int, default=4,
+                    help="steps folded into one engine launch set (same images in flight as that many replicas, ONE "
+                         "copy of the weights, 4x the rows per GEMM); 1 = one launch set per step")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="launch sets in flight per GPU: independent engine replicas (own HIP stream, workspace and "
+                         "weights) driven by host threads")
+    ap.add_argument("--precision", default="", help="c5r only: fp32 (default, the reference's arithmetic) or fp16")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even at world size 1 (exercises the gather path on a 1-GPU box)")
     a = ap.parse_args()
+    wl = WORKLOADS[a.workload]
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,11 +184,14 @@ def main():
 
     os.environ["LOCAL_RANK"] = str(local)
     os.environ["CYCLEDIFF_SYNTHETIC_WEIGHTS"] = "1"  # no checkpoints in this tree: seeded synthetic weights (opt-in)
-    args = get_config("experiments/bench_sd_c2.cfg", config_root=os.path.join(ROOT, "config"))
-    # A single stream of these kernels leaves the GPU under-occupied (most launches are wait-bound at 1-3
-    # workgroups per CU): two independent batches in flight on two HIP streams raise whole-GPU
-    # throughput ~1.4x. Replica r owns stream r, its own engine (workspace, split-K scratch) and weights.
+    args = get_config(wl["cfg"], config_root=os.path.join(ROOT, "config"))
+    if a.precision:
+        assert a.workload == "c5r", "--precision applies to the pixel-space workload"
+        args.gan.precision = a.precision
+    # Engine replicas: replica r owns stream r, its own engine (workspace, split-K scratch) and weights. With the
+    # default --coalesce 4 one replica already keeps 16 images in flight; more replicas only overlap kernel tails.
     n_rep = max(1, a.in_flight)
+    C = max(1, a.coalesce)
     os.environ["CYCLEDIFF_SHARE_SYNTH"] = "1" if n_rep > 1 else "0"  # generate the synthetic weights once per rank
     replicas = []
     for r in range(n_rep):
@@ -140,50 +200,69 @@ def main():
             torch.manual_seed(0)  # same weights on every rank and replica (main.py:66)
             replicas.append((st, get_model(args.model.name)(args).eval()))
     model = replicas[0][1]
-    eng = model.gan_wrapper.engine
+    wrapper = getattr(model, "gan_wrapper", None) or model.source_gan_wrapper
+    eng = wrapper.engine
     cda.Engine._SYNTH_CACHE.clear()
 
     # synthetic batch: global batch = B * world, rank r takes its contiguous slice (ShardSampler, trainer.py:288-293)
-    B = a.batch
+    B = a.batch or wl["batch"]
+    R = wl["res"]
     lo, hi = shard_range(B * world, world, rank)
     g = torch.Generator().manual_seed(1)
-    images = torch.rand(B * world, 3, 512, 512, generator=g)[lo:hi].to(dev)
+    images = torch.rand(B * world, 3, R, R, generator=g)[lo:hi].to(dev)
     sample_id = torch.arange(lo, hi, device=dev)
     src = ["source prompt %d" % i for i in range(lo, hi)]
     tgt = ["target prompt %d" % i for i in range(lo, hi)]
     torch.manual_seed(4 + rank)  # per-rank noise streams
+    # launch sets: K steps are issued C at a time (the last set may be smaller)
+    folded = {n: (images.repeat(n, 1, 1, 1), sample_id.repeat(n), src * n, tgt * n) for n in {C, a.steps % C} if n}
 
-    def compute(r):
+    def compute(r, n):
+        """one launch set of n steps (n * B triplets) on replica r"""
         st, m = replicas[r]
+        im, sid, s_txt, t_txt = folded[n]
         torch.cuda.set_device(dev)  # the current device is per host thread
         with torch.cuda.stream(st), torch.no_grad():
-            return m(sample_id=sample_id, original_image=images, encode_text=src, decode_text=tgt)
+            if wl["text"]:
+                return m(sample_id=sid, original_image=im, encode_text=s_txt, decode_text=t_txt)
+            return m(sample_id=sid, original_image=im)
 
     def gather(r, res):
+        """the per-step all-gather (trainer.py:833), once per step of the launch set, in step order"""
         (orig, img), loss, _ = res
         torch.cuda.current_stream(dev).wait_stream(replicas[r][0])
-        return gather_outputs((orig, img), loss)  # one all-gather per eval step (trainer.py:833)
+        out = None
+        for i in range(img.shape[0] // B):
+            sl = slice(i * B, (i + 1) * B)
+            out = gather_outputs((orig[sl], img[sl]), loss[sl])
+        return out
 
-    def step(r=0):
-        return gather(r, compute(r))
+    sets = [C] * (a.steps // C) + ([a.steps % C] if a.steps % C else [])
 
-    def run_steps(n):
-        """n steps, up to n_rep of them in flight: one host thread per replica computes, then the main thread does
-        that round's all-gathers in step order (parallel.run_in_flight)."""
-        return run_in_flight(n, n_rep, compute, gather)
+    def run_sets(sizes):
+        """launch sets in order, up to n_rep of them in flight: one host thread per replica computes, then the main
+        thread does that round's all-gathers in step order (parallel.run_in_flight)"""
+        return run_in_flight(len(sizes), n_rep, lambda r, i: compute(r, sizes[i]), gather, pass_index=True)
 
     def sync():
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):  # replica by replica: the first one tunes the GEMM table, the others reuse it
-        for r in range(n_rep):
-            step(r)
+    # warm-up: every replica runs every launch-set size once (the first one tunes unseen GEMM shapes, the others
+    # reuse the table), then whole sets until at least --warmup steps have run
+    done = 0
+    for r in range(n_rep):
+        for n in sorted(folded, reverse=True):
+            gather(r, compute(r, n))
             torch.cuda.synchronize(dev)
+            done += n
+    while done < a.warmup:
+        gather(0, compute(0, C))
+        done += C
     sync()
     t0 = time.perf_counter()
-    out = run_steps(a.steps)
+    out = run_sets(sets)  # exactly --steps steps
     sync()
     dt = time.perf_counter() - t0
     if dist.is_initialized():
@@ -193,39 +272,45 @@ def main():
     assert torch.isfinite(out[0][1]).all()
 
     res = None
-    # roofline of the dominant kernel (implicit-GEMM conv / GEMM family): one more identical step (all
-    # ranks take part in its gather) with per-launch HIP events on rank 0's engine stream;
-    # achieved = sum(2*M*N*K) / sum(launch durations)
+    # roofline of the dominant kernel (implicit-GEMM conv / GEMM family): one more launch set (all ranks take part in
+    # its gathers) with per-launch HIP events on rank 0's engine stream; achieved = sum(2*M*N*K) / sum(durations)
     if rank == 0:
         eng.prof_enable(True)
-    step()
+    gather(0, compute(0, C))
     sync()
     if rank == 0:
         ips = a.steps * B * world / dt
         n_launch, k_ms, k_flops = eng.prof_collect()
         eng.prof_enable(False)
-        ach = k_flops / (k_ms * 1e-3) / 1e12
-        traffic = pmc_traffic_per_launch()
+        f32 = getattr(wrapper, "precision", "") == "fp32"
+        peak = PEAK_F32_TFLOPS if f32 else PEAK_TFLOPS
+        ach = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        traffic = pmc_traffic_per_launch() if a.workload == "c2" else None
+        fmt = "fp16" if eng.lib.cd_act_format() == 1 else "bf16"
         res = {
-            "metric": "images/sec, SD-v1.4 512px CycleDiffusion 100+100 steps, 1/2/4/8 MI355X", "value": ips,
-            "unit": "images/s",
+            "metric": wl["metric"], "value": ips, "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp16" if eng.lib.cd_act_format() == 1 else "bf16", "data": "synthetic",
-            "config": {"workload": "C2: Stable-Diffusion-v1.4-shaped U-Net + KL-f8 VAE, 512x512, custom_steps=99 "
-                                   "white_box_steps=100 eta=0.1 skip 0, 1 trial, encoder scale 1, decoder CFG 3",
-                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                       "batches_in_flight_per_gpu": n_rep,
-                       "weights": model.gan_wrapper.weights_origin, "flop_per_image": F_IMG},
-            "roofline": {"bound": "mfma", "kernel": "k_conv_gemm (all tile instantiations)",
-                         "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS,
+            "dtype": "fp32" if f32 else fmt, "data": "synthetic",
+            "config": {"workload": wl["name"], "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": "dp%d" % world, "steps_per_launch_set": C, "launch_sets_in_flight_per_gpu": n_rep,
+                       "images_in_flight_per_gpu": B * C * n_rep,
+                       "storage": ("fp32 activations / weights, v_mfma_f32_32x32x2_f32 (the reference's arithmetic)" if f32
+                                   else "%s activations / weights, fp32 accumulate (BASELINE.json's C2 line says bf16: same "
+                                        "width and MFMA rate; fp16 keeps the DPM-Encoder's 1/sigma amplification 8x smaller, "
+                                        "DESIGN.md §5; bf16 is the CD_ACT_FP16=0 build)" % fmt),
+                       "weights": wrapper.weights_origin, "flop_per_image": wl["flop_per_image"]},
+            "roofline": {"bound": "mfma", "kernel": "k_conv_f32 (fp32 implicit GEMM)" if f32 else
+                         "k_conv_gemm (all tile instantiations)",
+                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC, profiles/)",
-                         "launches_per_step": n_launch, "kernel_ms_per_step": k_ms,
-                         "algorithmic_tflop_per_step": k_flops / 1e12,
-                         "whole_path_frac": ips * F_IMG / 1e12 / (world * PEAK_TFLOPS)},
+                         "operating_point": "one launch set of %d steps, single stream, per-launch HIP events" % C,
+                         "launches_per_step": n_launch / C, "kernel_ms_per_step": k_ms / C,
+                         "algorithmic_tflop_per_step": k_flops / 1e12 / C,
+                         "whole_path_frac": ips * wl["flop_per_image"] / 1e12 / (world * peak)},
         }
-        if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(eng, model.gan_wrapper.unet, model.gan_wrapper.vae)
+        if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
+            res["cpu_baseline"] = cpu_baseline(eng, wrapper.unet, wrapper.vae)
         print(json.dumps(res), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -48,7 +48,11 @@ struct TileCfg {
   static constexpr int MT = TM / 32, NT = TN / 32;
   static constexpr int KS = BK / 16;
   static constexpr int SWZ_SHIFT = (CPR == 8) ? 1 : 2;
-  static constexpr int EPI_LD = TN + 4;          // fp32 row stride of the epilogue staging tile
+  // the epilogue stages the wave tile through LDS in column chunks of CW (so the 64x160 / 64x128 wave tiles of the
+  // 320- and 256-wide block tiles fit in 160 KiB)
+  static constexpr int CW = TN >= 64 ? 64 : TN;  // chunk width in columns
+  static constexpr int EPI_LD = CW + 4;          // fp32 row stride of the epilogue staging chunk
+  static constexpr int PF = (MT * NT >= 8) ? 1 : 2;  // k-slices of fragments read ahead (register budget)
   static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   static constexpr int EPI_BYTES = NW * TM * EPI_LD * 4;
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
       for (int l = 0; l < LPT; ++l) issue(l, nxt);
     }
     read_frags(0);
-    if (KS > 1) read_frags(1);
+    if (KS > 1 && T::PF > 1) read_frags(1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           acc[i][j] = CD_MFMA_32x32x16(af[ks][i], bfr[ks][j], acc[i][j]);
-      if (ks + 2 < KS) read_frags(ks + 2);
+      if (ks + T::PF < KS) read_frags(ks + T::PF);
       __builtin_amdgcn_sched_barrier(0);
     }
     nxt = cur;
@@ -357,137 +361,147 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
     }
   }
 
-  // ---- epilogue: accumulators -> LDS (fp32, per-wave region) -> fused elementwise -> 16-B stores
+  // ---- epilogue: accumulators -> LDS (fp32, per-wave region, CW columns at a time) -> fused elementwise -> 16-B
+  // stores (8 lanes cover one 128-byte row segment). The staging region is private to the wave and a wave's LDS
+  // accesses execute in program order, so the chunks need no barrier between them (wave_barrier only pins the
+  // compiler's order). A register-resident variant (transposed MFMA blocks + v_permlane32_swap, no LDS round trip)
+  // measured SLOWER: its row-per-lane 16-byte stores touch 32-64 lines per instruction (DESIGN.md optimisation log).
+  constexpr int CW = T::CW, CJ = CW / 32;  // chunk width in columns / in 32-column MFMA blocks
   float* E = (float*)smem + wave * (TM * T::EPI_LD);
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-        const int col = j * 32 + frow;
-        E[row * T::EPI_LD + col] = acc[i][j][r] * p.alpha;
-      }
-  __syncthreads();
-
   const bool geglu = (p.act == ACT_GEGLU);
-  // GEGLU: packed columns come in blocks of 64 = [32 value | 32 gate] (k_pack_rows);
-  // only the value half produces output, at column (n/64)*32 + n%32.
-  constexpr int VPR_FULL = TN / 8;
-  const int vpr = geglu ? (TN / 16) : VPR_FULL;  // 8-wide vectors per row handled
-  const int rpp = 64 / vpr;                      // rows per pass
-  const int vr = lane / vpr, vc = lane % vpr;
   char* outp = (char*)p.out + (int64_t)zb * p.o_bs * (p.out_f32 ? 4 : 2);
-  // column-only quantities are the same for every row this lane handles: hoist them out of the row loop
-  const int col = geglu ? (vc / 4) * 64 + (vc % 4) * 8 : vc * 8;  // column inside the wave tile
-  const int n = n0 + wn * TN + col;                                // packed column
-  const int nvalid = (p.N - n) < 8 ? (p.N - n) : 8;
-  float bias_v[8], bias_g[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    bias_v[e] = (p.bias && e < nvalid) ? p.bias[n + e] : 0.0f;
-    bias_g[e] = (geglu && p.bias) ? p.bias[n + 32 + e] : 0.0f;
-  }
-  // optional fused GroupNorm statistics: per-channel sum / sum-of-squares of the FINAL values over each
-  // 32-row block of the output, written to stats[rowblock][2][N] (no atomics; the 32-row granularity is
-  // independent of the tile configuration and of the batch size)
-  float ssum[8], ssq[8];
+  for (int jc = 0; jc < NT; jc += CJ) {
+    const int cj = (NT - jc) < CJ ? (NT - jc) : CJ;  // blocks in this chunk (compile-time after unrolling)
+    const int cw = cj * 32;
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
-  for (int r0 = 0; r0 < TM; r0 += rpp) {
-    const int row = r0 + vr;
-    const int m = m0 + wm * TM + row;
-    if (row < TM && m < p.M && n < p.N) {
-    float v[8];
-    {
-      const f32x4 lo = *(const f32x4*)(E + row * T::EPI_LD + col);
-      const f32x4 hi = *(const f32x4*)(E + row * T::EPI_LD + col + 4);
-      v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-      v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < CJ; ++j)
+        if (j < cj) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+            E[row * T::EPI_LD + j * 32 + frow] = acc[i][jc + j][r] * p.alpha;
+          }
+        }
+    __builtin_amdgcn_wave_barrier();
+    // GEGLU: packed columns come in blocks of 64 = [32 value | 32 gate] (k_pack_rows) = one chunk; only the value
+    // half produces output, at column (n/64)*32 + n%32.
+    const int vpr = geglu ? 4 : (cw / 8);  // 8-wide vectors per row handled
+    const int rpp = 64 / vpr;              // rows per pass
+    const int vr = lane / vpr, vc = lane % vpr;
+    // column-only quantities are the same for every row this lane handles: hoist them out of the row loop
+    const int col = vc * 8;                            // column inside the chunk
+    const int n = n0 + wn * TN + jc * 32 + col;        // packed column
+    const int nvalid = (p.N - n) < 8 ? (p.N - n) : 8;
+    float bias_v[8], bias_g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bias_v[e] = (p.bias && e < nvalid) ? p.bias[n + e] : 0.0f;
+      bias_g[e] = (geglu && p.bias) ? p.bias[n + 32 + e] : 0.0f;
     }
+    // optional fused GroupNorm statistics: per-channel sum / sum-of-squares of the FINAL values over each
+    // 32-row block of the output, written to stats[rowblock][2][N] (no atomics; the 32-row granularity is
+    // independent of the tile configuration and of the batch size)
+    float ssum[8], ssq[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += bias_v[e];
-    int on = n;  // output column
-    if (geglu) {
-      float gt[8];
-      const f32x4 lo = *(const f32x4*)(E + row * T::EPI_LD + col + 32);
-      const f32x4 hi = *(const f32x4*)(E + row * T::EPI_LD + col + 36);
-      gt[0] = lo[0]; gt[1] = lo[1]; gt[2] = lo[2]; gt[3] = lo[3];
-      gt[4] = hi[0]; gt[5] = hi[1]; gt[6] = hi[2]; gt[7] = hi[3];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float gg = gt[e] + bias_g[e];
-        v[e] = v[e] * gelu_f(gg);
+    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+    for (int r0 = 0; r0 < TM; r0 += rpp) {
+      const int row = r0 + vr;
+      const int m = m0 + wm * TM + row;
+      if (row < TM && m < p.M && n < p.N) {
+      float v[8];
+      {
+        const f32x4 lo = *(const f32x4*)(E + row * T::EPI_LD + col);
+        const f32x4 hi = *(const f32x4*)(E + row * T::EPI_LD + col + 4);
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
       }
-      on = (n / 64) * 32 + (n % 64);
-    } else {
-      if (p.rowvec) {
-        const int rvi = (p.rows_per_vec >= p.M) ? 0 : m / p.rows_per_vec;  // shared timestep: one vector
-        const float* rv = p.rowvec + (int64_t)rvi * p.rowvec_ld + n;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += rv[e];
-      }
-      if (p.act == ACT_SILU) {
+      for (int e = 0; e < 8; ++e) v[e] += bias_v[e];
+      int on = n;  // output column
+      if (geglu) {
+        float gt[8];
+        const f32x4 lo = *(const f32x4*)(E + row * T::EPI_LD + col + 32);
+        const f32x4 hi = *(const f32x4*)(E + row * T::EPI_LD + col + 36);
+        gt[0] = lo[0]; gt[1] = lo[1]; gt[2] = lo[2]; gt[3] = lo[3];
+        gt[4] = hi[0]; gt[5] = hi[1]; gt[6] = hi[2]; gt[7] = hi[3];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-      } else if (p.act == ACT_GELU) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-      } else if (p.act == ACT_QGELU) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
-      }
-    }
-    if (p.resid) {
-      const bf16_t* rp = p.resid + (int64_t)zb * p.o_bs + (int64_t)m * p.resid_ld + on;
-      if (nvalid == 8 && ((p.resid_ld & 7) == 0)) {
-        float rr[8];
-        unpack8(*(const uint4*)rp, rr);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rr[e];
+        for (int e = 0; e < 8; ++e) {
+          const float gg = gt[e] + bias_g[e];
+          v[e] = v[e] * gelu_f(gg);
+        }
+        on = (n / 64) * 32 + (n % 64);
       } else {
+        if (p.rowvec) {
+          const int rvi = (p.rows_per_vec >= p.M) ? 0 : m / p.rows_per_vec;  // shared timestep: one vector
+          const float* rv = p.rowvec + (int64_t)rvi * p.rowvec_ld + n;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += bf2f(rp[e]);
+          for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += rv[e];
+        }
+        if (p.act == ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+        } else if (p.act == ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        } else if (p.act == ACT_QGELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
+        }
       }
-    }
-    if (p.out_f32) {
-      float* op = (float*)outp + (int64_t)m * p.out_ld + on;
-      if (nvalid == 8 && ((p.out_ld & 3) == 0)) {
-        *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
-        *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+      if (p.resid) {
+        const bf16_t* rp = p.resid + (int64_t)zb * p.o_bs + (int64_t)m * p.resid_ld + on;
+        if (nvalid == 8 && ((p.resid_ld & 7) == 0)) {
+          float rr[8];
+          unpack8(*(const uint4*)rp, rr);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rr[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += bf2f(rp[e]);
+        }
+      }
+      if (p.out_f32) {
+        float* op = (float*)outp + (int64_t)m * p.out_ld + on;
+        if (nvalid == 8 && ((p.out_ld & 3) == 0)) {
+          *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
+          *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (e < nvalid) op[e] = v[e];
+        }
       } else {
+        bf16_t* op = (bf16_t*)outp + (int64_t)m * p.out_ld + on;
+        if (nvalid == 8 && ((p.out_ld & 7) == 0)) {
+          *(uint4*)op = pack8(v);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) if (e < nvalid) op[e] = v[e];
+          for (int e = 0; e < 8; ++e) if (e < nvalid) op[e] = f2bf(v[e]);
+        }
       }
-    } else {
-      bf16_t* op = (bf16_t*)outp + (int64_t)m * p.out_ld + on;
-      if (nvalid == 8 && ((p.out_ld & 7) == 0)) {
-        *(uint4*)op = pack8(v);
-      } else {
+      if (p.stats) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) if (e < nvalid) op[e] = f2bf(v[e]);
+        for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
       }
-    }
-    if (p.stats) {
+      }  // valid row
+      if (p.stats && ((r0 + rpp) & 31) == 0) {
+        // end of a 32-row block: fold the lanes that share this column vector (same vc, different vr)
+        for (int o = vpr; o < 64; o <<= 1) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
-    }
-    }  // valid row
-    if (p.stats && ((r0 + rpp) & 31) == 0) {
-      // end of a 32-row block: fold the lanes that share this column vector (same vc, different vr)
-      for (int o = vpr; o < 64; o <<= 1) {
+          for (int e = 0; e < 8; ++e) { ssum[e] += __shfl_xor(ssum[e], o); ssq[e] += __shfl_xor(ssq[e], o); }
+        }
+        const int rb = (m0 + wm * TM + r0 + rpp - 32) >> 5;
+        if (vr == 0 && n < p.N && (rb << 5) < p.M) {
+          float* sp = p.stats + ((int64_t)zb * ((p.M + 31) >> 5) + rb) * 2 * p.N + n;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { ssum[e] += __shfl_xor(ssum[e], o); ssq[e] += __shfl_xor(ssq[e], o); }
+          for (int e = 0; e < 8; ++e) if (e < nvalid) { sp[e] = ssum[e]; sp[p.N + e] = ssq[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
       }
-      const int rb = (m0 + wm * TM + r0 + rpp - 32) >> 5;
-      if (vr == 0 && n < p.N && (rb << 5) < p.M) {
-        float* sp = p.stats + ((int64_t)zb * ((p.M + 31) >> 5) + rb) * 2 * p.N + n;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) if (e < nvalid) { sp[e] = ssum[e]; sp[p.N + e] = ssq[e]; }
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
     }
   }
 #endif  // __HIP_DEVICE_COMPILE__
@@ -535,7 +549,14 @@ const CfgInfo kCfgs[] = {
     {17, 64, 128, 64, "64x128 w2x2 s6"},
     {18, 256, 128, 32, "256x128 w4x4 s3"},
     {19, 256, 128, 64, "256x128 w8x2 s3"},
+    // 320-wide block tiles: N = 320 / 640 / 1280 / 2560 of the SD / LDM U-Nets split with no padded columns and the
+    // A panel is read once per 320 output channels; BK = 64 only (a 320-row B tile does not split over BK = 32 rows)
+    {20, 256, 320, 160, "256x320 w4x2 s2"},
+    {21, 128, 320, 160, "128x320 w2x2 s2"},
+    {22, 256, 256, 128, "256x256 w4x2 s2"},
+    {23, 128, 320, 160, "128x320 w4x2 s2"},
 };
+inline bool cfg_needs_bk64(int id) { return id >= 20 && id <= 23; }
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 }  // namespace gemm_detail
@@ -575,6 +596,16 @@ void dispatch(hipStream_t st, const ConvGemmParams& p, int id) {
     case 19:
       if constexpr (BK == 64) launch_cfg<256, 128, 64, 8, 2, 3>(st, p);
       else launch_cfg<256, 128, 32, 4, 2, 3>(st, p);
+      break;
+    case 20: case 21: case 22: case 23:
+      if constexpr (BK == 64) {
+        if (id == 20) launch_cfg<256, 320, 64, 4, 2, 2>(st, p);
+        else if (id == 21) launch_cfg<128, 320, 64, 2, 2, 2>(st, p);
+        else if (id == 22) launch_cfg<256, 256, 64, 4, 2, 2>(st, p);
+        else launch_cfg<128, 320, 64, 4, 2, 2>(st, p);
+      } else {
+        CD_CHECK(false, "conv_gemm: tile configuration %d needs channel counts that are multiples of 64", id);
+      }
       break;
     default: CD_CHECK(false, "conv_gemm: unknown tile configuration %d", id);
   }
@@ -730,8 +761,10 @@ int tuned_config(hipStream_t st, const ConvGemmParams& p, bool k64) {
     const bool use64 = k64 && bi == 0;
     if (bi == 1 && split > 1) continue;
     if (split > 1 && !tune_splitk) continue;
-    if (p.act == ACT_GEGLU && c.TN < 64) continue;
+    if (p.act == ACT_GEGLU && (c.TN % 64) != 0) continue;
     if (c.BM >= 256 && p.M < 256) continue;
+    if (cfg_needs_bk64(c.id) && !use64) continue;
+    if (c.BN == 320 && (p.N % 320) != 0) continue;
     const int64_t tiles = (int64_t)ceil_div(p.M, c.BM) * ceil_div(p.N, c.BN) * p.nbatch;
     if (split > 1) {
       if (!sk.scratch || t128 >= 400 || nk < 4 * split || tiles * split > 2048) continue;
@@ -783,7 +816,8 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   const CfgInfo* ci = nullptr;
   for (int i = 0; i < kNumCfgs; ++i) if (kCfgs[i].id == id) ci = &kCfgs[i];
   CD_CHECK(ci, "conv_gemm: unknown tile configuration %d", id);
-  if (p.act == ACT_GEGLU && ci->TN < 64) { id = 2; ci = &kCfgs[1]; }
+  if (p.act == ACT_GEGLU && (ci->TN % 64) != 0) { id = 2; ci = &kCfgs[1]; }
+  if (cfg_needs_bk64(id)) CD_CHECK(k64, "conv_gemm: tile configuration %d needs channel counts that are multiples of 64", id);
   g_last_cfg = ci->name;
   KernelProfiler* prof = g_conv_prof;
   hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -72,11 +72,12 @@ def gather_outputs(tensors, loss=None, num_total_examples=None):
     return _gather_nested(tensors, num_total_examples), _concat(loss, num_total_examples)
 
 
-def run_in_flight(n_steps, n_replicas, compute, finish):
+def run_in_flight(n_steps, n_replicas, compute, finish, pass_index=False):
     """Run `n_steps` independent steps with up to `n_replicas` of them in flight (bench.py: one engine replica per
     HIP stream). Each round starts one host thread per replica running `compute(replica) -> result`; when the round's
     threads have joined, the MAIN thread calls `finish(replica, result)` for the round's steps in step order - that is
     where collectives go, so every rank issues them in the same order no matter how its threads were scheduled.
+    With pass_index the call is `compute(replica, step_index)`.
     Returns the last `finish` value. A replica that raises aborts the run with that exception."""
     import threading
     out, done = None, 0
@@ -84,9 +85,9 @@ def run_in_flight(n_steps, n_replicas, compute, finish):
         k = min(n_replicas, n_steps - done)
         res, err = {}, {}
 
-        def work(r):
+        def work(r, base=done):
             try:
-                res[r] = compute(r)
+                res[r] = compute(r, base + r) if pass_index else compute(r)
             except BaseException as e:  # noqa: BLE001 - re-raised on the main thread
                 err[r] = e
 

@@ -70,6 +70,17 @@ CONV_CASES = [
     ("3x3_ragged_M", 1, 64, 0, 10, 10, 64, 3, 1, 1, False, False, True, False, True, 0, 0),
     ("3x3_1280_8x8", 2, 1280, 0, 8, 8, 1280, 3, 1, 1, False, False, True, True, True, 0, 0),
     ("3x3_2560_1280_skip", 1, 1280, 1280, 8, 8, 1280, 3, 1, 1, False, False, True, False, False, 0, 0),
+    # 320- / 256-wide block tiles (chunked epilogue, 64x160 and 64x128 wave tiles); ragged M, N = 640 (two 320 tiles),
+    # N not a multiple of the tile (masked columns), residual + time-embedding row vector, split-K on top
+    ("3x3_320_320_16_t20", 2, 320, 0, 16, 16, 320, 3, 1, 1, False, False, True, True, True, 0, 20),
+    ("3x3_320_320_16_t21", 2, 320, 0, 16, 16, 320, 3, 1, 1, False, False, True, True, True, 0, 21),
+    ("3x3_320_320_16_t23", 2, 320, 0, 16, 16, 320, 3, 1, 1, False, False, True, True, True, 0, 23),
+    ("3x3_320_640_t22", 2, 320, 0, 16, 16, 640, 3, 1, 1, False, False, True, True, True, 0, 22),
+    ("1x1_640_640_t20_silu", 3, 640, 0, 10, 10, 640, 1, 1, 0, False, False, True, False, True, 1, 20),
+    ("3x3_concat_320_t21_ragged", 1, 192, 128, 10, 10, 320, 3, 1, 1, False, False, True, False, True, 0, 21),
+    ("3x3_N192_t22_masked", 2, 64, 0, 16, 16, 192, 3, 1, 1, False, False, True, False, False, 0, 22),
+    ("3x3_1280_8x8_t20_split4", 2, 1280, 0, 8, 8, 1280, 3, 1, 1, False, False, True, True, True, 0, 20 | (4 << 8)),
+    ("3x3_up_640_t23", 1, 640, 0, 8, 8, 640, 3, 1, 1, False, True, True, False, False, 0, 23),
     # split-K (tile | split << 8): K ranges that start mid-tap / in the second concat source, ragged M,
     # more splits than K steps (empty ranges), fused epilogue after the fix-up
     ("3x3_1280_8x8_split4", 2, 1280, 0, 8, 8, 1280, 3, 1, 1, False, False, True, True, True, 0, 8 | (4 << 8)),
@@ -134,7 +145,7 @@ def test_conv_geglu(engine, report):
     h = F.linear(x[0, :, :, 0].t(), w, b)
     val, gate = h.chunk(2, dim=-1)
     ref = (val * F.gelu(gate)).t()[None, :, :, None]
-    for tile in (1, 2):
+    for tile in (1, 2, 22, 6):
         got = _ops.conv2d(engine, x, w, pad=0, bias=b, geglu=True, tile=tile)
         _check(report, "conv2d/geglu_t%d" % tile, got, ref, rel=5e-3, mean=3e-3)
 
