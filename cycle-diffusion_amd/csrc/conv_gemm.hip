@@ -507,17 +507,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+
 template <int BM, int BN, int BK, int WM, int WN, int NSTAGE>
-void launch_cfg(hipStream_t st, const ConvGemmParams& p) {
+int launch_cfg(hipStream_t st, const ConvGemmParams& p) {
   using T = TileCfg<BM, BN, BK, WM, WN, NSTAGE>;
+  const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+  const int split = p.splitk > 1 ? p.splitk : 1;
   static std::once_flag attr_once;  // engines on several host threads launch the same instantiation
   auto kern = k_conv_gemm<BM, BN, BK, WM, WN, NSTAGE>;
   std::call_once(attr_once, [&]() {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   T::LDS_BYTES));
   });
-  const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-  const int split = p.splitk > 1 ? p.splitk : 1;
   if (split > 1) {
     const SplitKWorkspace& ws = g_conv_splitk;
     CD_CHECK(p.sk_scratch && p.sk_flags, "conv_gemm: split-K without workspace");
@@ -525,6 +526,7 @@ void launch_cfg(hipStream_t st, const ConvGemmParams& p) {
              "conv_gemm: split-K workspace too small");
   }
   hipLaunchKernelGGL(kern, dim3(tiles, split, p.nbatch), dim3(64 * T::NW), T::LDS_BYTES, st, p);
+  return 0;
 }
 
 struct CfgInfo { int id, BM, BN, TN; const char* name; };
@@ -564,51 +566,52 @@ thread_local SplitKWorkspace g_conv_splitk;
 namespace gemm_detail {
 
 template <int BK>
-void dispatch(hipStream_t st, const ConvGemmParams& p, int id) {
+int dispatch(hipStream_t st, const ConvGemmParams& p, int id) {
   switch (id) {
-    case 1: launch_cfg<128, 128, BK, 2, 2, 2>(st, p); break;
-    case 2: launch_cfg<128, 64, BK, 4, 1, 2>(st, p); break;
-    case 3: launch_cfg<64, 64, BK, 2, 2, 2>(st, p); break;
-    case 4: launch_cfg<128, 128, BK, 2, 2, 3>(st, p); break;
-    case 5: launch_cfg<256, 128, BK, 4, 2, 3>(st, p); break;
-    case 6: launch_cfg<128, 256, BK, 2, 4, 3>(st, p); break;
-    case 7: launch_cfg<128, 64, BK, 4, 1, 4>(st, p); break;
-    case 8: launch_cfg<64, 64, BK, 2, 2, 4>(st, p); break;
+    case 1: return launch_cfg<128, 128, BK, 2, 2, 2>(st, p);
+    case 2: return launch_cfg<128, 64, BK, 4, 1, 2>(st, p);
+    case 3: return launch_cfg<64, 64, BK, 2, 2, 2>(st, p);
+    case 4: return launch_cfg<128, 128, BK, 2, 2, 3>(st, p);
+    case 5: return launch_cfg<256, 128, BK, 4, 2, 3>(st, p);
+    case 6: return launch_cfg<128, 256, BK, 2, 4, 3>(st, p);
+    case 7: return launch_cfg<128, 64, BK, 4, 1, 4>(st, p);
+    case 8: return launch_cfg<64, 64, BK, 2, 2, 4>(st, p);
     case 9:
-      if constexpr (BK == 64) launch_cfg<256, 64, 64, 8, 1, 4>(st, p);
-      else launch_cfg<128, 64, 32, 4, 1, 4>(st, p);  // 8x1 waves need >= 8 glds rows groups per B tile
-      break;
-    case 10: launch_cfg<128, 128, BK, 2, 2, 4>(st, p); break;
-    case 11: launch_cfg<64, 128, BK, 2, 2, 4>(st, p); break;
-    case 12: launch_cfg<128, 64, BK, 4, 1, 3>(st, p); break;
+      if constexpr (BK == 64) return launch_cfg<256, 64, 64, 8, 1, 4>(st, p);
+      else return launch_cfg<128, 64, 32, 4, 1, 4>(st, p);  // 8x1 waves need >= 8 glds rows groups per B tile
+     
+    case 10: return launch_cfg<128, 128, BK, 2, 2, 4>(st, p);
+    case 11: return launch_cfg<64, 128, BK, 2, 2, 4>(st, p);
+    case 12: return launch_cfg<128, 64, BK, 4, 1, 3>(st, p);
     case 13:
-      if constexpr (BK == 64) launch_cfg<256, 64, 64, 8, 1, 3>(st, p);
-      else launch_cfg<128, 64, 32, 4, 1, 3>(st, p);
-      break;
-    case 14: launch_cfg<128, 128, BK, 4, 2, 3>(st, p); break;
-    case 15: launch_cfg<64, 64, BK, 2, 2, 8>(st, p); break;
-    case 16: launch_cfg<128, 64, BK, 4, 1, 6>(st, p); break;
-    case 17: launch_cfg<64, 128, BK, 2, 2, 6>(st, p); break;
+      if constexpr (BK == 64) return launch_cfg<256, 64, 64, 8, 1, 3>(st, p);
+      else return launch_cfg<128, 64, 32, 4, 1, 3>(st, p);
+     
+    case 14: return launch_cfg<128, 128, BK, 4, 2, 3>(st, p);
+    case 15: return launch_cfg<64, 64, BK, 2, 2, 8>(st, p);
+    case 16: return launch_cfg<128, 64, BK, 4, 1, 6>(st, p);
+    case 17: return launch_cfg<64, 128, BK, 2, 2, 6>(st, p);
     case 18:
-      if constexpr (BK == 64) launch_cfg<256, 128, 64, 4, 4, 3>(st, p);
-      else launch_cfg<256, 128, 32, 4, 2, 3>(st, p);  // 16 waves need >= 16 row groups per B tile
-      break;
+      if constexpr (BK == 64) return launch_cfg<256, 128, 64, 4, 4, 3>(st, p);
+      else return launch_cfg<256, 128, 32, 4, 2, 3>(st, p);  // 16 waves need >= 16 row groups per B tile
+     
     case 19:
-      if constexpr (BK == 64) launch_cfg<256, 128, 64, 8, 2, 3>(st, p);
-      else launch_cfg<256, 128, 32, 4, 2, 3>(st, p);
-      break;
+      if constexpr (BK == 64) return launch_cfg<256, 128, 64, 8, 2, 3>(st, p);
+      else return launch_cfg<256, 128, 32, 4, 2, 3>(st, p);
+     
     case 20: case 21: case 22: case 23:
       if constexpr (BK == 64) {
-        if (id == 20) launch_cfg<256, 320, 64, 4, 2, 2>(st, p);
-        else if (id == 21) launch_cfg<128, 320, 64, 2, 2, 2>(st, p);
-        else if (id == 22) launch_cfg<256, 256, 64, 4, 2, 2>(st, p);
-        else launch_cfg<128, 320, 64, 4, 2, 2>(st, p);
+        if (id == 20) return launch_cfg<256, 320, 64, 4, 2, 2>(st, p);
+        else if (id == 21) return launch_cfg<128, 320, 64, 2, 2, 2>(st, p);
+        else if (id == 22) return launch_cfg<256, 256, 64, 4, 2, 2>(st, p);
+        else return launch_cfg<128, 320, 64, 4, 2, 2>(st, p);
       } else {
         CD_CHECK(false, "conv_gemm: tile configuration %d needs channel counts that are multiples of 64", id);
       }
-      break;
+      return 0;
     default: CD_CHECK(false, "conv_gemm: unknown tile configuration %d", id);
   }
+  return 0;
 }
 
 thread_local const char* g_last_cfg = "";
@@ -808,8 +811,8 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   bool k64 = (p.C0 % 64 == 0) && (p.C1 % 64 == 0);
   int id = p.tile ? p.tile : tuned_config(st, p, k64);
   if (id & (1 << 16)) k64 = false;  // tuner (or an explicit tile | 1<<16) asks for the BK=32 variant
-  id &= 0xffff;
   ConvGemmParams pk = p;
+  id &= 0xffff;
   if ((id >> 8) > 1) pk.splitk = id >> 8;  // from the tuner, or packed into an explicit `tile` (tests, sweeps)
   id &= 0xff;
   if (pk.splitk > 1 && !pk.sk_scratch) { pk.sk_scratch = g_conv_splitk.scratch; pk.sk_flags = g_conv_splitk.flags; }
@@ -822,7 +825,7 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   KernelProfiler* prof = g_conv_prof;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (prof && prof->enabled) {
-    char what[96] = "";
+    char what[112] = "";
     if (prof->verbose)
       snprintf(what, sizeof(what), "M%d N%d K%d k%d s%d%s%s z%d act%d | %s x%d", p.M, p.N, p.Ktot, p.KH, p.stride,
                p.up ? " up" : "", p.src1 ? " cat" : "", p.nbatch, p.act, ci->name, pk.splitk > 1 ? pk.splitk : 1);

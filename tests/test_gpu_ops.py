@@ -6,6 +6,7 @@ max-abs error is bounded by ~2^-8 of the output scale (REL_TOL) and the mean err
 Scheduler kernels are fp32 with the reference's operation order and must be bit-exact.
 """
 import math
+import os
 import zlib
 
 import numpy as np
