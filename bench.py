@@ -263,6 +263,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     out = run_sets(sets)  # exactly --steps steps
+    t_enq = time.perf_counter() - t0  # host time to ENQUEUE the steps (world size 1: nothing in the loop waits)
     sync()
     dt = time.perf_counter() - t0
     if dist.is_initialized():
@@ -295,6 +296,8 @@ def main():
             "config": {"workload": wl["name"], "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world, "steps_per_launch_set": C, "launch_sets_in_flight_per_gpu": n_rep,
                        "images_in_flight_per_gpu": B * C * n_rep,
+                       "distributed": "nccl(RCCL) process group" if dist.is_initialized() else "single process",
+                       "host_enqueue_ms_per_step": (1e3 * t_enq / a.steps) if not dist.is_initialized() else None,
                        "storage": ("fp32 activations / weights, v_mfma_f32_32x32x2_f32 (the reference's arithmetic)" if f32
                                    else "%s activations / weights, fp32 accumulate (BASELINE.json's C2 line says bf16: same "
                                         "width and MFMA rate; fp16 keeps the DPM-Encoder's 1/sigma amplification 8x smaller, "

@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float gg = gt[e] + bias_g[e];
-          v[e] = v[e] * gelu_f(gg);
+          v[e] = v[e] * gelu_fast(gg);
         }
         on = (n / 64) * 32 + (n % 64);
       } else {
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
           for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
         } else if (p.act == ACT_GELU) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+          for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
         } else if (p.act == ACT_QGELU) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));

@@ -10,6 +10,8 @@
 //
 // One tile shape per problem size and a fixed k-ascending accumulation order: results are bit-reproducible across
 // processes (no autotuner, no split-K on this path).
+#include <stdio.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -369,6 +371,18 @@ void launch_conv_gemm_f32(hipStream_t st, const ConvGemmParams& p) {
   CD_CHECK(p.act != ACT_GEGLU && p.act != ACT_QGELU && !p.stats && p.splitk <= 1, "conv_f32: unsupported epilogue");
   CD_CHECK((p.ld0 % 4) == 0 && (p.src1 == nullptr || (p.ld1 % 4) == 0), "conv_f32: ld must be a multiple of 4");
   CD_CHECK(((uintptr_t)p.src0 & 15) == 0 && ((uintptr_t)p.wgt & 15) == 0, "conv_f32: 16-B alignment");
+  KernelProfiler* prof = g_conv_prof;  // bench.py's roofline leg: per-launch HIP events on the launch stream
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (prof && prof->enabled) {
+    char what[96] = "";
+    if (prof->verbose) snprintf(what, sizeof(what), "f32 M%d N%d K%d k%d s%d", p.M, p.N, p.Ktot, p.KH, p.stride);
+    prof->next_pair(&e0, &e1, 2.0 * (double)p.M * (double)p.N * (double)p.Ktot, what);
+    (void)hipEventRecord(e0, st);
+  }
+  struct Closer {
+    hipEvent_t e; hipStream_t s;
+    ~Closer() { if (e) (void)hipEventRecord(e, s); }
+  } closer{e1, st};
   const int64_t big = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 64);
   if (big >= 256) {
     hipLaunchKernelGGL((k_conv_f32<128, 64>), dim3((unsigned)big), dim3(256), 0, st, p);

@@ -1,19 +1,20 @@
 #!/bin/bash
-# Round profile of bench.py on the GPU box: the bench line (tunes, writes the tile-table cache), then kernel
-# stats of an already-tuned single-stream process. Writes under gpurun_out/prof_bench/; copy the summaries into profiles/.
+# Round profile of bench.py on the GPU box: the bench line, then rocprofv3 kernel stats of the same single-stream
+# process (shipped tile table preloaded: no autotuning launches). Writes under gpurun_out/prof_bench/; the summaries
+# are then copied into profiles/.
 set -u
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_bench
 mkdir -p $OUT
-export CYCLEDIFF_TUNE_CACHE=/tmp/cd_tune.txt
 export PYTHONPATH=$ROOT
 cd /tmp
-timeout 600 python $ROOT/bench.py --steps 8 --warmup 1 --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
+timeout 900 python $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json | cut -c1-400
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- python $ROOT/bench.py --steps 1 --warmup 0 --in-flight 1 --no-cpu-baseline > $OUT/stats.log 2>&1
-find $OUT/stats -name "*kernel_trace.csv" -delete
-# (HBM-traffic PMC passes: scripts/profile_unet_pmc.sh - rocprofv3 counter collection crashes on the full bench)
-find $OUT -name "*counter_collection.csv" -delete
+# 4 steps = one launch set timed + one warm-up set + the event-instrumented set: 3 identical launch sets in the trace
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- python $ROOT/bench.py --steps 4 --warmup 0 --no-cpu-baseline > $OUT/stats.log 2>&1
+python $ROOT/scripts/kernel_breakdown.py $OUT/stats > $OUT/kernel_breakdown.txt 2>&1
+head -30 $OUT/kernel_breakdown.txt
 find $OUT -name "*kernel_trace.csv" -delete
+find $OUT -name "*counter_collection.csv" -delete
 ls -la $OUT $OUT/stats 2>/dev/null | head -30
