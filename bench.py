@@ -261,11 +261,12 @@ def main():
         gather(0, compute(0, C))
         done += C
     sync()
+    c0 = time.process_time()
     t0 = time.perf_counter()
     out = run_sets(sets)  # exactly --steps steps
-    t_enq = time.perf_counter() - t0  # host time to ENQUEUE the steps (world size 1: nothing in the loop waits)
     sync()
     dt = time.perf_counter() - t0
+    host_cpu = time.process_time() - c0  # CPU seconds of this rank (all its threads) over the timed region
     if dist.is_initialized():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -297,7 +298,7 @@ def main():
                        "parallelism": "dp%d" % world, "steps_per_launch_set": C, "launch_sets_in_flight_per_gpu": n_rep,
                        "images_in_flight_per_gpu": B * C * n_rep,
                        "distributed": "nccl(RCCL) process group" if dist.is_initialized() else "single process",
-                       "host_enqueue_ms_per_step": (1e3 * t_enq / a.steps) if not dist.is_initialized() else None,
+                       "host_cpu_cores_used": host_cpu / dt,  # ~1: one launching thread (it spin-waits in stream syncs)
                        "storage": ("fp32 activations / weights, v_mfma_f32_32x32x2_f32 (the reference's arithmetic)" if f32
                                    else "%s activations / weights, fp32 accumulate (BASELINE.json's C2 line says bf16: same "
                                         "width and MFMA rate; fp16 keeps the DPM-Encoder's 1/sigma amplification 8x smaller, "

@@ -34,7 +34,15 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, variant=None):
+    """variant=None: the product library (fp16 storage). variant="bf16": the same sources with -DCD_ACT_FP16=0
+    into lib/libcyclediff_bf16.so - only for the measurement-hygiene bench line (CYCLEDIFF_LIB=... python bench.py)."""
+    global OBJDIR, LIB
+    defines = []
+    if variant == "bf16":
+        OBJDIR = os.path.join(HERE, "build", "bf16")
+        LIB = os.path.join(LIBDIR, "libcyclediff_bf16.so")
+        defines = ["-DCD_ACT_FP16=0"]
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
@@ -49,7 +57,7 @@ def build(force=False, verbose=False):
             extra = ["-ffp-contract=off"] if s == "sched.hip" else []  # scheduler math: reference op order, no FMA
             if s == "conv_gemm.hip":  # the register epilogue of the 256x320 tile is 10 fully unrolled 32x32 blocks
                 extra = ["-mllvm", "-pragma-unroll-threshold=1048576"]
-            jobs.append([hipcc] + FLAGS + extra + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + defines + extra + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -69,4 +77,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, variant="bf16" if "--bf16" in sys.argv else None))

@@ -4,7 +4,8 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cycle_diffusion_amd as cda
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8

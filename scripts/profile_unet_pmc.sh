@@ -1,17 +1,16 @@
 #!/bin/bash
-# HBM-side traffic (rocprofv3 PMC, one counter per pass) of one SD-v1 U-Net forward at B=4 and B=8.
-# (The full bench.py process crashes inside rocprofv3's counter collection; one forward has the same
-# kernel population as a C2 step: 100 B=4 encode + 100 B=8 CFG decode forwards.)
+# HBM-side traffic (rocprofv3 PMC, one counter per pass) of one SD-v1 U-Net forward at B'=16 and B'=32 - the two
+# forward types of a coalesced C2 launch set (16 images through the DPM-Encoder, 32 rows through the CFG decode).
+# (The full bench.py process crashes inside rocprofv3's counter collection; one forward has the same kernel
+# population as the launch set: 99 B'=16 + 99 B'=32 forwards.)
 set -u
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_pmc
 mkdir -p $OUT
-export CYCLEDIFF_TUNE_CACHE=/tmp/cd_tune.txt
 export PYTHONPATH=$ROOT
 cd /tmp
-for B in 4 8; do
-  timeout 300 python $ROOT/scripts/bench_unet.py $B 2 > $OUT/unet_b$B.log 2>&1   # tunes, writes the cache
+for B in 16 32; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_$c
     timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- python $ROOT/scripts/bench_unet.py $B 1 > $OUT/pmc_${c}_b$B.log 2>&1
