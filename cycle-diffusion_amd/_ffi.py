@@ -29,7 +29,7 @@ class NetDesc(C.Structure):
         ("use_spatial_transformer", C.c_int), ("context_dim", C.c_int), ("transformer_depth", C.c_int),
         ("use_scale_shift_norm", C.c_int), ("resblock_updown", C.c_int), ("conv_resample", C.c_int),
         ("z_channels", C.c_int), ("embed_dim", C.c_int), ("double_z", C.c_int),
-        ("precision", C.c_int), ("reserved", C.c_int * 7),
+        ("precision", C.c_int), ("n_embed", C.c_int), ("reserved", C.c_int * 6),
     ]
 
 

@@ -392,10 +392,12 @@ int cd_vae_encode(cd_handle h, int net, const float* img, const float* noise, ui
   const int cin = v->desc.in_channels, cp = round_up(cin, 32), hl = R / v->factor;
   bf16_t* xin = (bf16_t*)h->arena.alloc((size_t)B * R * R * cp * 2);
   launch_nchw_to_nhwc(h->st, img, xin, B, cin, R * R, cp, 1.f, 0.f, 0);
-  const int mch = 2 * v->desc.embed_dim;
+  const int mch = v->moments_channels;
   float* mom = (float*)h->arena.alloc((size_t)B * hl * hl * mch * 4);
   v->encode_moments(c, xin, B, R, mom);
-  launch_posterior_sample(h->st, mom, mch, noise, seed, z0, B, v->desc.embed_dim, hl * hl, scale, sample ? 0 : 1);
+  // VQ first stage: no distribution, the encoding is the quant_conv output itself (ddpm.py get_first_stage_encoding)
+  const bool vq = v->codebook != nullptr;
+  launch_posterior_sample(h->st, mom, mch, noise, seed, z0, B, v->desc.embed_dim, hl * hl, scale, (sample && !vq) ? 0 : 1);
   CD_API_END
 }
 
@@ -409,7 +411,10 @@ int cd_vae_decode(cd_handle h, int net, const float* z0, int B, int hlat, float 
   Ctx c = h->ctx();
   const int zc = v->desc.embed_dim, cp = round_up(zc, 32), R = hlat * v->factor, co = v->desc.out_channels;
   bf16_t* zin = (bf16_t*)h->arena.alloc((size_t)B * hlat * hlat * cp * 2);
-  launch_nchw_to_nhwc(h->st, z0, zin, B, zc, hlat * hlat, cp, 1.0f / scale, 0.f, 0);  // z = 1/scale * z (ddpm.py:705)
+  if (v->codebook)  // VQModelInterface.decode: quantise to the codebook first (autoencoder.py:274-280)
+    launch_vq_quantize(h->st, z0, 1.0f / scale, v->codebook, v->n_embed, zc, B, hlat * hlat, zin, cp);
+  else
+    launch_nchw_to_nhwc(h->st, z0, zin, B, zc, hlat * hlat, cp, 1.0f / scale, 0.f, 0);  // z = 1/scale * z (ddpm.py:705)
   float* o = (float*)h->arena.alloc((size_t)B * R * R * co * 4);
   v->decode(c, zin, B, hlat, o);
   launch_nhwc_to_nchw(h->st, o, 1, co, img, B, co, R * R, out_mul, out_add);

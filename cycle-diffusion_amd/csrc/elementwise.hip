@@ -253,6 +253,36 @@ __global__ void k_posterior_sample(const float* __restrict__ mom, int ld, const 
   }
 }
 
+// one thread per latent vector, codebook staged in LDS ([n_embed][zc] fp32: 96 KB for the 8192 x 3 codebook of VQ-f4)
+__global__ __launch_bounds__(256) void k_vq_quantize(const float* __restrict__ z, float in_mul,
+                                                     const float* __restrict__ codebook, int n_embed, int zc, int B,
+                                                     int HW, bf16_t* __restrict__ out, int Cpad) {
+  extern __shared__ float cb[];
+  for (int i = threadIdx.x; i < n_embed * zc; i += blockDim.x) cb[i] = codebook[i];
+  __syncthreads();
+  const int64_t n = (int64_t)B * HW;
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < n; v += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(v / HW), pix = (int)(v - (int64_t)b * HW);
+    float zv[8];
+    float z2 = 0.f;
+    for (int c = 0; c < zc; ++c) {
+      zv[c] = z[((int64_t)b * zc + c) * HW + pix] * in_mul;
+      z2 += zv[c] * zv[c];
+    }
+    int best = 0;
+    float bd = INFINITY;
+    for (int k = 0; k < n_embed; ++k) {
+      const float* e = cb + k * zc;
+      float e2 = 0.f, dot = 0.f;
+      for (int c = 0; c < zc; ++c) { e2 += e[c] * e[c]; dot += zv[c] * e[c]; }
+      const float d = (z2 + e2) - 2.0f * dot;
+      if (d < bd) { bd = d; best = k; }  // strict: the first minimum wins, as torch.argmin
+    }
+    bf16_t* o = out + v * Cpad;
+    for (int c = 0; c < Cpad; ++c) o[c] = f2bf(c < zc ? zv[c] + (cb[best * zc + c] - zv[c]) : 0.f);
+  }
+}
+
 __global__ void k_fill_f32(float* p, float v, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
@@ -315,6 +345,21 @@ void launch_posterior_sample(hipStream_t st, const float* mom, int ld, const flo
   const int64_t n = (int64_t)B * zc * HW;
   hipLaunchKernelGGL(k_posterior_sample, dim3(ew_grid(n)), dim3(256), 0, st, mom, ld, noise, seed, z,
                      B, zc, HW, scale, use_mean);
+}
+void launch_vq_quantize(hipStream_t st, const float* z, float in_mul, const float* codebook, int n_embed, int zc,
+                        int B, int HW, bf16_t* out, int Cpad) {
+  CD_CHECK(zc >= 1 && zc <= 8 && n_embed > 0, "vq_quantize: embed_dim %d / n_embed %d", zc, n_embed);
+  const size_t lds = (size_t)n_embed * zc * sizeof(float);
+  CD_CHECK(lds <= 150 * 1024, "vq_quantize: codebook of %zu bytes does not fit LDS", lds);
+  static bool attr = false;
+  if (!attr) {
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_vq_quantize, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr = true;
+  }
+  const int64_t n = (int64_t)B * HW;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 512) grid = 512;
+  hipLaunchKernelGGL(k_vq_quantize, dim3(grid), dim3(256), lds, st, z, in_mul, codebook, n_embed, zc, B, HW, out, Cpad);
 }
 void launch_embed_tokens(hipStream_t st, const int* ids, const float* tok, const float* pos, bf16_t* out, int B,
                          int L, int D, int vocab) {

@@ -206,6 +206,9 @@ class VAE : public Net {
   virtual void encode_moments(Ctx& c, const bf16_t* img_nhwc, int B, int R, float* moments) = 0;  // fp32 [B*h*w][2*zc]
   virtual void decode(Ctx& c, const bf16_t* z_nhwc, int B, int h, float* img) = 0;                 // fp32 [B*R*R][3]
   int z_channels = 4, factor = 8;
+  int moments_channels = 8;          // channels of encode_moments' output: 2 * embed_dim (KL) or embed_dim (VQ)
+  const float* codebook = nullptr;   // VQ first stage: [n_embed][embed_dim] fp32, else null
+  int n_embed = 0;
 };
 std::unique_ptr<VAE> make_vae_kl(const cd_net_desc& d);
 

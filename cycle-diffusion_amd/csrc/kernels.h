@@ -202,6 +202,11 @@ void launch_upsample2(hipStream_t st, const bf16_t* x, bf16_t* y, int B, int H, 
 void launch_posterior_sample(hipStream_t st, const float* mom, int ld, const float* noise,
                              uint64_t seed, float* z, int B, int zc, int HW, float scale,
                              int use_mean);
+// VectorQuantizer2.forward of taming-transformers (git master; not vendored by the reference, README.md:85-91) as
+// VQModelInterface.decode calls it (autoencoder.py:274-282): per latent vector z (fp32 NCHW * in_mul) the nearest
+// codebook row by d = (|z|^2 + |e|^2) - 2 z.e (first minimum), output z + (e - z) -> 16-bit NHWC padded to Cpad
+void launch_vq_quantize(hipStream_t st, const float* z, float in_mul, const float* codebook, int n_embed, int zc,
+                        int B, int HW, bf16_t* out, int Cpad);
 void launch_fill_f32(hipStream_t st, float* p, float v, int64_t n);
 // ViT token assembly (OpenAI CLIP VisionTransformer.forward): out[b][0] = cls + pos[0]; out[b][1+t] = patch[b][t] + pos[1+t]
 void launch_vit_tokens(hipStream_t st, const bf16_t* patch, const float* cls, const float* pos, bf16_t* out, int B,

@@ -176,14 +176,19 @@ class VAEKL : public VAE {
 
 VAEKL::VAEKL(const cd_net_desc& d) {
   desc = d;
-  CD_CHECK(d.precision == CD_PREC_16, "the KL autoencoder runs in the 16-bit format only");
+  CD_CHECK(d.precision == CD_PREC_16, "the autoencoders run in the 16-bit format only");
   ch_ = d.model_channels; nres_ = d.num_res_blocks; nlev_ = d.n_mult;
   for (int i = 0; i < nlev_; ++i) mult_.push_back(d.channel_mult[i]);
   z_channels = d.z_channels; embed_ = d.embed_dim; in_ch_ = d.in_channels; out_ch_ = d.out_channels;
   factor = 1 << (nlev_ - 1);
-  CD_CHECK(d.double_z, "AutoencoderKL needs double_z");
-  CD_CHECK(d.n_attn == 0, "attn_resolutions inside the VAE levels are not used by the KL-f8 configs");
-  moments_ = 2 * z_channels;
+  // AutoencoderKL: double_z, Gaussian posterior (autoencoder.py:285-333). VQModelInterface (n_embed > 0): the encoder
+  // emits z_channels directly and decode() snaps to the codebook first (autoencoder.py:264-282)
+  CD_CHECK((d.double_z != 0) != (d.n_embed > 0), "first stage must be either KL (double_z) or VQ (n_embed > 0)");
+  CD_CHECK(d.n_attn == 0, "attn_resolutions inside the VAE levels are not used by the f4 / f8 configs");
+  const int zmul = d.double_z ? 2 : 1;
+  moments_ = zmul * z_channels;
+  moments_channels = zmul * embed_;
+  n_embed = d.n_embed;
   // ---- encoder (model.py:368-459)
   e_in_ = mk_conv(params, "encoder.conv_in", ch_, in_ch_, 3);
   int bin = ch_;
@@ -201,7 +206,12 @@ VAEKL::VAEKL(const cd_net_desc& d) {
   e_m2_ = mk_rn(params, "encoder.mid.block_2", bin, bin);
   e_no_ = mk_gn(params, "encoder.norm_out", bin);
   e_out_ = mk_conv(params, "encoder.conv_out", moments_, bin, 3);
-  quant_ = mk_conv(params, "quant_conv", 2 * embed_, moments_, 1);
+  quant_ = mk_conv(params, "quant_conv", zmul * embed_, moments_, 1);
+  if (n_embed > 0) {
+    float* cb = params.new_vec(n_embed * embed_);
+    params.mat_f32("quantize.embedding.weight", cb, n_embed, embed_);
+    codebook = cb;
+  }
   // ---- decoder (model.py:462-568)
   pq_ = mk_conv(params, "post_quant_conv", z_channels, embed_, 1);
   bin = ch_ * mult_[nlev_ - 1];
@@ -241,7 +251,7 @@ void VAEKL::encode_moments(Ctx& c, const bf16_t* img, int B, int R, float* momen
   HIP_CHECK(hipMemsetAsync(mo.p, 0, (size_t)mo.rows() * cp * 2, c.st));
   ConvOpts oo; oo.out = mo.p; oo.out_ld = cp;
   conv_fwd(c, *e_out_, n, nullptr, oo);
-  ConvOpts oq; oq.pad = 0; oq.out_f32 = true; oq.out = moments; oq.out_ld = 2 * embed_;
+  ConvOpts oq; oq.pad = 0; oq.out_f32 = true; oq.out = moments; oq.out_ld = moments_channels;
   conv_fwd(c, *quant_, mo, nullptr, oq);
   c.arena->release(mk);
 }

@@ -12,9 +12,10 @@ from ._ffi import NetDesc, check, ptr
 def make_desc(kind, *, image_size, in_channels, out_channels, model_channels, num_res_blocks, channel_mult,
               attn=(), num_heads=-1, num_head_channels=-1, use_spatial_transformer=False, context_dim=0,
               transformer_depth=1, use_scale_shift_norm=False, resblock_updown=False, conv_resample=True,
-              z_channels=0, embed_dim=0, double_z=False, precision=_ffi.CD_PREC_16):
+              z_channels=0, embed_dim=0, double_z=False, precision=_ffi.CD_PREC_16, n_embed=0):
     d = NetDesc()
     d.precision = int(precision)
+    d.n_embed = int(n_embed)
     d.kind = kind
     d.image_size = image_size
     d.in_channels, d.out_channels = in_channels, out_channels
@@ -55,6 +56,21 @@ def kl_f8_vae_desc():
     """v1-inference.yaml:46-65 (first_stage_config ddconfig)"""
     return make_desc(_ffi.CD_NET_VAE_KL, image_size=0, in_channels=3, out_channels=3, model_channels=128,
                      num_res_blocks=2, channel_mult=(1, 2, 4, 4), z_channels=4, embed_dim=4, double_z=True)
+
+
+def vq_f4_vae_desc():
+    """first_stage_config of the unconditional LDMs (model/lib/latentdiff/models/ldm/{celeba256,ffhq256}/config.yaml):
+    VQModelInterface, embed_dim 3, n_embed 8192, ch 128, ch_mult (1, 2, 4), 2 res blocks, double_z False"""
+    return make_desc(_ffi.CD_NET_VAE_KL, image_size=0, in_channels=3, out_channels=3, model_channels=128,
+                     num_res_blocks=2, channel_mult=(1, 2, 4), z_channels=3, embed_dim=3, double_z=False, n_embed=8192)
+
+
+def ldm_uncond_unet_desc(image_size=64):
+    """unet_config of celeba256 / ffhq256 (same files): UNetModel with AttentionBlocks (legacy QKV order), 224
+    channels, mult (1, 2, 3, 4), attention at downsample rates 2 / 4 / 8, 32-channel heads, no conditioning"""
+    return make_desc(_ffi.CD_NET_UNET_OPENAI, image_size=image_size, in_channels=3, out_channels=3,
+                     model_channels=224, num_res_blocks=2, channel_mult=(1, 2, 3, 4), attn=(8, 4, 2),
+                     num_head_channels=32)
 
 
 def clip_text_desc(width=768, layers=12, heads=12, mlp=3072, vocab=49408, positions=77):

@@ -23,5 +23,6 @@ def get_gan_wrapper(args, target=False):
         from .latent_text_wrapper import SDStochasticTextWrapper
         return SDStochasticTextWrapper(**kwargs)
     if args.gan_type == "LatentDiffStochastic":
-        raise NotImplementedError("unconditional LDM (VQ-f4 first stage) wrapper: SURVEY.md §8(f) rank 4")
+        from .latent_wrapper import LatentDiffStochasticWrapper
+        return LatentDiffStochasticWrapper(**kwargs)
     raise ValueError(args.gan_type)

@@ -1,0 +1,99 @@
+"""Unconditional latent-diffusion wrapper on the HIP engine: drop-in for LatentDiffStochasticWrapper
+(model/gan_wrapper/latentdiff_stochastic_wrapper.py:175-316, `gan_type = LatentDiffStochastic`; the reference's
+FFHQ -> CelebA-HQ experiment, config/experiments/translate_ffhq256_to_celeba256_latentdiff_ddim_eta01.cfg).
+
+Same constructor kwargs, encode(image, class_label=None) -> z [B, white_box_steps * C * h * w], forward(z,
+class_label=None) -> img in [0, 1], attributes .resolution .latent_dim .enforce_class_input.
+
+Path: (image - 0.5) * 2 -> VQ-f4 encoder + quant_conv (VQModelInterface.encode: no sampling, scale factor 1) ->
+DPM-Encoder with the unconditional U-Net -> [x_T, eps...]; forward: decode with the injected eps ->
+DDIMSampler.refine (eta 1: re-noise to the DDIM level refine_steps - 1, then refine_steps random steps;
+ddim.py:114-168, 339-393) -> nearest-codebook quantisation + post_quant_conv + decoder -> (x + 1) / 2.
+Class-conditional models (`enforce_class_input`, cin256) are not used by any reference config and raise.
+"""
+import os
+
+import torch
+
+from .. import _ffi, schedule
+from ..engine import ldm_uncond_unet_desc, vq_f4_vae_desc
+from ..runtime import get_engine, load_or_init_weights
+
+# source_model_type -> (U-Net descriptor, first-stage descriptor, linear_start, linear_end, scale_factor) from
+# model/lib/latentdiff/models/ldm/<type>/config.yaml
+MODEL_TYPES = {
+    "celeba256": (ldm_uncond_unet_desc, vq_f4_vae_desc, 0.0015, 0.0195, 1.0),
+    "ffhq256": (ldm_uncond_unet_desc, vq_f4_vae_desc, 0.0015, 0.0195, 1.0),
+}
+
+
+class LatentDiffStochasticWrapper(torch.nn.Module):
+
+    def __init__(self, source_model_type, custom_steps, eta, white_box_steps, refine_steps=0,
+                 enforce_class_input=None, unconditional_guidance_scale=None, device=None, noise_on_cpu=False,
+                 unet_desc=None, vae_desc=None):
+        super().__init__()
+        if enforce_class_input:
+            raise NotImplementedError("class-conditional LDMs (cin256) are not used by the reference configs")
+        self.enforce_class_input = enforce_class_input
+        self.unconditional_guidance_scale = unconditional_guidance_scale
+        self.refine_steps = int(refine_steps)
+        self.custom_steps, self.eta, self.white_box_steps = int(custom_steps), float(eta), int(white_box_steps)
+        assert self.eta > 0
+        self.noise_on_cpu = bool(noise_on_cpu)
+        if source_model_type not in MODEL_TYPES:
+            raise NotImplementedError(source_model_type)
+        udesc_fn, vdesc_fn, ls, le, self.scale_factor = MODEL_TYPES[source_model_type]
+        self.engine = get_engine(device)
+        udesc = unet_desc if unet_desc is not None else udesc_fn()
+        vdesc = vae_desc if vae_desc is not None else vdesc_fn()
+        self.channels, self.image_size = udesc.in_channels, udesc.image_size
+        self.unet = self.engine.create_net(udesc)
+        self.vae = self.engine.create_net(vdesc)
+        self.vae_factor = 2 ** (vdesc.n_mult - 1)
+        ckpt = os.path.join("ckpts", "ldm_models", "ldm", source_model_type, "model.ckpt")  # prepare_latentdiff (:16)
+        self.weights_origin = load_or_init_weights(self.engine, ckpt, {
+            self.unet: "model.diffusion_model.", self.vae: "first_stage_model."})
+        self.resolution = self.image_size * self.vae_factor
+        self.latent_dim = self.image_size ** 2 * self.channels * self.white_box_steps
+        self.alphas_cumprod = schedule.latent_alphas_cumprod(1000, ls, le)
+        self._anchor = torch.nn.Parameter(torch.zeros(1, device=self.engine.device), requires_grad=True)
+
+    def _randn(self, n, shape):
+        if self.noise_on_cpu:  # one tensor per reference draw, in the reference's order
+            return torch.stack([torch.randn(shape) for _ in range(n)], 0).to(self.device)
+        return torch.randn((n,) + tuple(shape), device=self.device)
+
+    def encode(self, image, class_label=None):
+        image = (image - 0.5) * 2.0
+        assert image.shape[2] == image.shape[3] == self.resolution
+        x0 = self.engine.vae_encode(self.vae, image.to(self.device, torch.float32), sample=False,
+                                    scale=self.scale_factor)
+        sch = schedule.DDIMSchedule(self.alphas_cumprod, self.custom_steps, self.eta)
+        K = len(sch)
+        assert self.white_box_steps == K + 1, "the reference configs use white_box_steps = custom_steps + 1"
+        # draw order of _ddpm_ddim_encoding: randn_like(x0), then one randn per sample_xt_next except index 0
+        nz = self._randn(K, tuple(x0.shape))
+        z = self.engine.dpm_encode(self.unet, _ffi.CD_SCHED_DDIM, x0, sch.coef_encode(), noise=nz, last_uses_x0=True)
+        z = z.view(x0.shape[0], -1)
+        assert z.shape[1] == self.latent_dim
+        return z
+
+    def generate(self, z, class_label=None):
+        bsz = z.shape[0]
+        zz = z.view(bsz, self.white_box_steps, self.channels, self.image_size, self.image_size).contiguous()
+        sch = schedule.DDIMSchedule(self.alphas_cumprod, self.custom_steps, self.eta)
+        x = self.engine.ddim_decode(self.unet, _ffi.CD_SCHED_DDIM, zz, sch.coef_decode())
+        if self.refine_steps > 0:  # convsample_ddim: refine with eta = 1 (latentdiff_stochastic_wrapper.py:70-78)
+            rs = schedule.DDIMSchedule(self.alphas_cumprod, self.custom_steps, 1.0)
+            nz = self._randn(self.refine_steps + 1, tuple(x.shape))
+            x = self.engine.pix_refine(self.unet, _ffi.CD_SCHED_DDIM, x, rs.coef_refine(self.refine_steps), noise=nz)
+        return self.engine.vae_decode(self.vae, x, scale=self.scale_factor)
+
+    def forward(self, z, class_label=None):
+        img = self.generate(z.to(self.device, torch.float32), class_label)
+        return (img + 1.0) / 2.0  # post_process Normalize(mean=-1, std=2)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device

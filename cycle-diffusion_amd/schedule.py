@@ -60,6 +60,15 @@ class DDIMSchedule:
     def coef_decode(self, skip_steps=0):
         return _pack(self._rows(len(self) - skip_steps))
 
+    def coef_refine(self, refine_steps):
+        """DDIMSampler.refine (ddim.py:114-168, 339-393) on a schedule built with eta = 1: rows 0..R-1 = the R random
+        p_sample_ddim steps by `index`, row R = the re-noising to the DDIM level R - 1 (ddim.py:349-351)."""
+        assert 0 < refine_steps < len(self)
+        rows = self._rows(refine_steps)
+        aR = self.a[refine_steps - 1]
+        rows.append((np.sqrt(aR), np.sqrt(ONE - aR), 0.0, 0.0, 0.0, 0.0, 1.0, 0))
+        return _pack(rows)
+
     def _rows(self, K):
         rows = []
         for k in range(K):

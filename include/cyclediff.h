@@ -36,7 +36,8 @@ enum { CD_PREC_16 = 0, CD_PREC_F32 = 1 };
  *   UNET_OPENAI : ldm/modules/diffusionmodules/openaimodel.py:413-470 (SD v1, LDM text2img) and
  *                 model/lib/ddpm_ddim/models/improved_ddpm/unet.py:401-470 (i_DDPM AFHQ)
  *   UNET_HO     : model/lib/ddpm_ddim/models/ddpm/diffusion.py:192-290
- *   VAE_KL      : ldm/models/autoencoder.py:285-333 + diffusionmodules/model.py:368-568
+ *   VAE_KL      : ldm/models/autoencoder.py:285-333 + diffusionmodules/model.py:368-568; with n_embed > 0 the VQ-f4
+ *                 first stage (VQModelInterface) of the unconditional LDMs
  *   CLIP_TEXT   : the HF `CLIPTextModel` behind FrozenCLIPEmbedder (ldm/modules/encoders/modules.py:136-161);
  *                 descriptor fields reused: model_channels = width (768), num_res_blocks = layers (12),
  *                 num_heads (12), context_dim = MLP width (3072), in_channels = vocabulary (49408),
@@ -68,7 +69,11 @@ typedef struct cd_net_desc {
    * (`use_fp16=False`, improved_ddpm/script_util.py:15). U-Nets without SpatialTransformer blocks only: the
    * pixel-space DDPMs of ddpm_ddim_wrapper.py, whose 'ddim' chain needs eps_hat at fp32 resolution. */
   int precision;
-  int reserved[7];
+  /* VAE_KL only: > 0 selects the VQ first stage of the unconditional LDMs (VQModelInterface,
+   * model/lib/latentdiff/ldm/models/autoencoder.py:264-282, `n_embed` codebook rows of width embed_dim): double_z = 0,
+   * encode = encoder + quant_conv (no sampling), decode = nearest-codebook quantisation + post_quant_conv + decoder */
+  int n_embed;
+  int reserved[6];
 } cd_net_desc;
 
 /* Per-step scheduler coefficients, evaluated by the host in fp32 in the reference's operation

@@ -247,6 +247,69 @@ def gen_pixel_refine():
     _pixel_chain("c5_tiny_iddpm_chain", build_ref_iddpm(), 107, 100, 85, 10, 12, (2468, 1357))
 
 
+TINY_LDM_UNCOND = dict(image_size=16, in_channels=3, out_channels=3, model_channels=32, num_res_blocks=1,
+                       attention_resolutions=[2, 4], channel_mult=[1, 2, 3], num_head_channels=32)
+TINY_VQ = dict(ch=32, out_ch=3, ch_mult=(1, 2, 4), num_res_blocks=1, attn_resolutions=[], in_channels=3,
+               resolution=64, z_channels=3, double_z=False, dropout=0.0)
+
+
+class RefVQ(torch.nn.Module):
+    """VQModelInterface glue (model/lib/latentdiff/ldm/models/autoencoder.py:264-282) around the reference Encoder /
+    Decoder; the quantiser itself lives in taming-transformers (absent): oracle.nets.vq_quantize restates it."""
+
+    def __init__(self, cfg=TINY_VQ, embed_dim=3, n_embed=256):
+        super().__init__()
+        ref_import.setup()
+        from ldm.modules.diffusionmodules.model import Decoder, Encoder
+        with ref_import.quiet():
+            self.encoder = Encoder(**cfg)
+            self.decoder = Decoder(**cfg)
+        self.quantize = torch.nn.Module()
+        self.quantize.embedding = torch.nn.Embedding(n_embed, embed_dim)
+        self.quant_conv = torch.nn.Conv2d(cfg["z_channels"], embed_dim, 1)
+        self.post_quant_conv = torch.nn.Conv2d(embed_dim, cfg["z_channels"], 1)
+
+    def encode(self, x):
+        return self.quant_conv(self.encoder(x))
+
+    def decode(self, h):
+        return self.decoder(self.post_quant_conv(nets.vq_quantize(h, self.quantize.embedding.weight)))
+
+
+def gen_ldm_uncond():
+    """gan_type LatentDiffStochastic on small networks: VQ first stage -> reference DDIMSampler encode (49 steps, eta
+    0.1, linear 0.0015..0.0195 schedule of the celeba256 / ffhq256 LDMs) -> sample_with_eps -> refine (10 steps,
+    eta 1; ddim.py:114-168,339-393) -> VQ decode -> (x + 1) / 2 (latentdiff_stochastic_wrapper.py:59-80,262-305)."""
+    Sampler = ref_import.ddim_sampler_cls()
+    S, R = 49, 10
+    with torch.no_grad():
+        u = build_ref_sd_unet(TINY_LDM_UNCOND)
+        uns, _ = load_synth(u, 108)
+        v = RefVQ()
+        vns, _ = load_synth(v, 109)
+        shim = ref_import.LatentShim(u, linear_start=0.0015, linear_end=0.0195)
+        image = torch.rand((1, 3, 64, 64), generator=torch.Generator().manual_seed(13))
+        x0 = v.encode((image - 0.5) * 2.0)
+        torch.manual_seed(5151)
+        with ref_import.quiet():
+            z_list = Sampler(shim).ddpm_ddim_encoding(S, batch_size=1, shape=(3, 16, 16), eta=0.1, white_box_steps=S + 1,
+                                                      verbose=False, x0=x0)
+            z = torch.stack(z_list, dim=1)
+            x_dec, _ = Sampler(shim).sample_with_eps(S, z[:, 1:], batch_size=1, shape=(3, 16, 16), eta=0.1,
+                                                     verbose=False, x_T=z[:, 0])
+        torch.manual_seed(6262)
+        with ref_import.quiet():
+            x_ref, _ = Sampler(shim).refine(S, refine_steps=R, batch_size=1, shape=(3, 16, 16), eta=1, verbose=False,
+                                            x0=x_dec)
+        img0 = (v.decode(x_dec) + 1.0) / 2.0
+        img = (v.decode(x_ref) + 1.0) / 2.0
+        slots = [0, 1, 25, 49]
+        save("ldm_uncond_tiny", unet_names=json.dumps(uns), vae_names=json.dumps(vns), useed=108, vseed=109, img_seed=13,
+             noise_seed=5151, refine_seed=6262, steps=S, refine_steps=R, x0=x0, z_sub=z[:, slots],
+             z_sub_slots=np.asarray(slots), z_norms=z.flatten(2).norm(dim=2), x_dec=x_dec, x_ref=x_ref, img_norefine=img0,
+             img=img)
+
+
 def gen_xtr_text():
     """LDM text encoder: the reference's vendored x-transformers TransformerWrapper on seeded weights / ids."""
     ref_import.setup()
@@ -270,7 +333,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     todo = dict(schedule=gen_schedule, nets=gen_nets, latent=gen_latent_cycle, c1=gen_c1, xtr=gen_xtr_text,
-                pixel_refine=gen_pixel_refine)
+                pixel_refine=gen_pixel_refine, ldm_uncond=gen_ldm_uncond)
     for k, fn in todo.items():
         if not a.only or a.only == k:
             fn()

@@ -260,6 +260,23 @@ def posterior_sample(moments, noise=None):
     return mean + torch.exp(0.5 * logvar) * noise
 
 
+def vq_quantize(z, codebook):
+    """VectorQuantizer2.forward of taming-transformers (taming/modules/vqvae/quantize.py, git master - the version the
+    reference's README installs, README.md:85-91; NOT vendored and not installed here, so this restatement of the
+    published algorithm is unpinned by the reference: "parity unpinned" for this one operator) as
+    VQModelInterface.decode calls it (model/lib/latentdiff/ldm/models/autoencoder.py:274-280):
+    z [B, C, H, W] -> nearest codebook row per position by d = |z|^2 + |e|^2 - 2 z.e, returned with the
+    straight-through form z + (z_q - z)."""
+    zp = z.permute(0, 2, 3, 1).contiguous()
+    zf = zp.view(-1, zp.shape[-1])
+    d = torch.sum(zf ** 2, dim=1, keepdim=True) + torch.sum(codebook ** 2, dim=1) - 2 * torch.einsum(
+        "bd,dn->bn", zf, codebook.t())
+    idx = torch.argmin(d, dim=1)
+    zq = codebook[idx].view(zp.shape)
+    zq = zp + (zq - zp)
+    return zq.permute(0, 3, 1, 2).contiguous()
+
+
 def vae_decode(sd, cfg, z):
     """post_quant_conv + Decoder.forward (autoencoder.py:330-333; model.py:535-568)."""
     h = _conv(sd, "decoder.conv_in", _conv(sd, "post_quant_conv", z, padding=0))

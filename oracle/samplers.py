@@ -96,6 +96,25 @@ def latent_decode(eps_model, x_T, eps_list, S, eta, skip_steps=0, alphas_cumprod
     return x
 
 
+def latent_refine(eps_model, x0, S, refine_steps, noises, alphas_cumprod=None):
+    """DDIMSampler.refine / _refine (ddim.py:114-168, 339-393): make_schedule(S, eta=1); re-noise x0 to the DDIM
+    level refine_steps - 1 with noises[0], then refine_steps random p_sample_ddim steps (ddim.py:503-543) with
+    noises[1:] (one draw per step, index 0 included)."""
+    ac = sd_alphas_cumprod() if alphas_cumprod is None else alphas_cumprod
+    ts, a, a_prev, sig, r = ddim_tables(ac, S, 1.0)
+    B = x0.shape[0]
+    at = a[refine_steps - 1]
+    x = at.sqrt() * x0 + (1 - at).sqrt() * noises[0]
+    for i in range(refine_steps):
+        k = refine_steps - i - 1
+        t = torch.full((B,), int(ts[k]), dtype=torch.long)
+        a_t, a_p, s_t, r_t = _full(B, a[k]), _full(B, a_prev[k]), _full(B, sig[k]), _full(B, r[k])
+        e = eps_model(x, t)
+        pred_x0 = (x - r_t * e) / a_t.sqrt()
+        x = a_p.sqrt() * pred_x0 + (1. - a_p - s_t ** 2).sqrt() * e + s_t * noises[1 + i] * 1.0
+    return x
+
+
 def cfg_model(unet_fn, c, uc, scale):
     """ddim.py:550-559: scale==1 -> cond only, 0 -> uncond only, else 2B batch + combine."""
     def f(x, t):

@@ -16,6 +16,9 @@ TINY_IDDPM_CFG = nets.OpenAIUNetCfg(in_channels=3, out_channels=6, model_channel
                                     channel_mult=(1, 2, 2), attn_ds=(2,), num_heads=4, num_head_channels=32,
                                     use_scale_shift_norm=True, resblock_updown=True)
 TINY_VAE_CFG = nets.VAECfg(ch=32, ch_mult=(1, 2, 4), num_res_blocks=1)
+TINY_LDM_UNCOND_CFG = nets.OpenAIUNetCfg(in_channels=3, out_channels=3, model_channels=32, num_res_blocks=1,
+                                         channel_mult=(1, 2, 3), attn_ds=(2, 4), num_head_channels=32)
+TINY_VQ_CFG = nets.VAECfg(ch=32, ch_mult=(1, 2, 4), num_res_blocks=1, z_channels=3, embed_dim=3)
 TOY_HO_CFG = nets.HoCfg(ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(16,), resolution=32)
 
 

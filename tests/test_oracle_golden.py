@@ -113,3 +113,35 @@ def test_c1_toy_ddpm_ddim_eta():
 
 def test_c1_toy_ddpm_ddpm_type():
     _c1("c1_toy_ddpm_ddpmtype", 20, None, "ddpm")
+
+
+def test_ldm_uncond_chain_with_refine():
+    """gan_type LatentDiffStochastic on small networks (oracle/gen_golden.py:gen_ldm_uncond): VQ first stage, 49-step
+    DPM-Encoder, decode, 10-step eta-1 refinement, VQ decode - the oracle restatement against the reference's
+    DDIMSampler / Encoder / Decoder run (the codebook lookup itself is the oracle's on both sides: taming-transformers
+    is not installed, see oracle/nets.py:vq_quantize)."""
+    import json
+    fx = gu.load("ldm_uncond_tiny")
+    usd = nets.synth_state_dict(json.loads(str(fx["unet_names"])), int(fx["useed"]))
+    vsd = nets.synth_state_dict(json.loads(str(fx["vae_names"])), int(fx["vseed"]))
+    S, R = int(fx["steps"]), int(fx["refine_steps"])
+    ac = samplers.sd_alphas_cumprod(1000, 0.0015, 0.0195)
+    image = torch.rand((1, 3, 64, 64), generator=torch.Generator().manual_seed(int(fx["img_seed"])))
+    unet = lambda x, t: nets.openai_unet(usd, gu.TINY_LDM_UNCOND_CFG, x, t)
+    with torch.no_grad():
+        x0 = nets.vae_encode_moments(vsd, gu.TINY_VQ_CFG, (image - 0.5) * 2.0)
+        _close(x0, fx["x0"])
+        nz = gu.latent_noise(int(fx["noise_seed"]), x0.shape, S)
+        z = samplers.latent_encode(unet, x0, S, 0.1, nz, white_box_steps=S + 1, alphas_cumprod=ac)
+        zs = torch.stack(z, 1)
+        slots = [int(s) for s in fx["z_sub_slots"]]
+        _close(zs[:, slots], fx["z_sub"], atol=2e-3, rtol=2e-3)  # eps = (...)/sigma amplifies fp32 order differences
+        x_dec = samplers.latent_decode(unet, zs[:, 0], zs[:, 1:], S, 0.1, alphas_cumprod=ac)
+        _close(x_dec, fx["x_dec"], atol=2e-4)
+        torch.manual_seed(int(fx["refine_seed"]))
+        rn = [torch.randn(x0.shape) for _ in range(R + 1)]
+        x_ref = samplers.latent_refine(unet, torch.as_tensor(fx["x_dec"]), S, R, rn, alphas_cumprod=ac)
+        _close(x_ref, fx["x_ref"], atol=2e-4)
+        img = (nets.vae_decode(vsd, gu.TINY_VQ_CFG, nets.vq_quantize(torch.as_tensor(fx["x_ref"]),
+                                                                     vsd["quantize.embedding.weight"])) + 1.0) / 2.0
+        _close(img, fx["img"], atol=1e-4)
