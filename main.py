@@ -28,6 +28,8 @@ def main(argv=None):
     ap.add_argument("--per_device_eval_batch_size", type=int, default=4)
     ap.add_argument("--range", type=int, nargs=2, default=None, metavar=("START", "END"))
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--grid", action="store_true",
+                    help="also write the reference's multi_image pair grids (original | translated, 8 per row)")
     ap.add_argument("--synthetic-weights", action="store_true",
                     help="run on seeded synthetic weights when a checkpoint file is missing (default: error, as the "
                          "reference's torch.load); recorded as weights_origin in metrics.json")
@@ -57,7 +59,7 @@ def main(argv=None):
     ds = TripletDataset(a.data, wrapper.resolution, start, end)
     os.makedirs(a.output_dir, exist_ok=True)
     dev = torch.device("cuda", local)
-    rows = []
+    rows, grid_pairs = [], []
     for step_idx in shard_indices(len(ds), a.per_device_eval_batch_size, world, rank):
         batch = collate([ds[i] for i in step_idx])
         kw = {"sample_id": batch["sample_id"].to(dev), "original_image": batch["original_image"].to(dev)}
@@ -65,6 +67,8 @@ def main(argv=None):
             kw.update(encode_text=batch["encode_text"], decode_text=batch["decode_text"])
         with torch.no_grad():
             (orig, img), _loss, _ = model(**kw)
+        if a.grid and rank == 0 and len(grid_pairs) < 100:
+            grid_pairs.append((orig.detach().clamp(0, 1).cpu(), img.detach().clamp(0, 1).cpu()))
         for j in range(img.shape[0]):
             o, g = orig[j].clamp(0, 1).cpu(), img[j].clamp(0, 1).cpu()
             sid = int(batch["sample_id"][j])
@@ -84,6 +88,9 @@ def main(argv=None):
         rows = [r for part in gathered for r in part]
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and grid_pairs:
+        from cycle_diffusion_amd.utils.visualize import visualize
+        visualize((torch.cat([p[0] for p in grid_pairs]), torch.cat([p[1] for p in grid_pairs])), "eval", a.output_dir, 0)
     if rank == 0:
         rows = list({r["sample_id"]: r for r in rows}.values())  # the sampler's wrap-around padding repeats samples
         rows.sort(key=lambda r: r["sample_id"])

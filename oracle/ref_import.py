@@ -2,8 +2,8 @@
 
   * oracle/gen_golden.py runs the reference on seeded inputs and commits small fixtures under
     tests/golden/;
-  * tests/test_oracle_vs_reference.py compares the oracle restatement with the live reference
-    whenever /root/reference is present (it is absent on the GPU box).
+  * tests/test_oracle_vs_reference.py (and test_oracle_xtr.py) compare the oracle restatement with the live
+    reference whenever /root/reference is present (it is absent on the GPU box: the tests skip there).
 
 TEST INFRASTRUCTURE ONLY. Nothing in the product imports this file. Nothing is copied from the
 reference: its files are imported from where they lie, read-only, with four tiny stub modules for
