@@ -558,7 +558,7 @@ const CfgInfo kCfgs[] = {
     {22, 256, 256, 128, "256x256 w4x2 s2"},
     {23, 128, 320, 160, "128x320 w4x2 s2"},
 };
-inline bool cfg_needs_bk64(int id) { return id >= 20 && id <= 23; }
+inline bool cfg_needs_bk64(int id) { return id == 20 || id == 21 || id == 23; }
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 }  // namespace gemm_detail
@@ -606,6 +606,9 @@ int dispatch(hipStream_t st, const ConvGemmParams& p, int id) {
         else if (id == 22) return launch_cfg<256, 256, 64, 4, 2, 2>(st, p);
         else return launch_cfg<128, 320, 64, 4, 2, 2>(st, p);
       } else {
+        // 256x256 also exists with 32-deep K steps and a 4-deep ring (3 stages in flight instead of 1: the short-K
+        // projections wait on Infinity-Cache latency, not on bandwidth); the 320-wide B tiles do not split over 32 rows
+        if (id == 22) return launch_cfg<256, 256, 32, 4, 2, 4>(st, p);
         CD_CHECK(false, "conv_gemm: tile configuration %d needs channel counts that are multiples of 64", id);
       }
       return 0;

@@ -70,6 +70,11 @@ def _run(cls, fx_name, res, ctx_dim, report):
         x_tgt = w.engine.ddim_decode(w.unet, _ffi.CD_SCHED_DDIM, z.contiguous(), w._schedule().coef_decode(0),
                                      ctx_c=w.cond_stage(["target"]).cuda(), ctx_uc=w.cond_stage([""]).cuda(),
                                      guidance=float(fx["dec_scale"]))
+        # same-text decode (encoder scale 1): the 99-step full-size cycle must return the encoder's own x0
+        x_same = w.engine.ddim_decode(w.unet, _ffi.CD_SCHED_DDIM, z.contiguous(), w._schedule().coef_decode(0),
+                                      ctx_c=w.cond_stage(["source"]).cuda(), guidance=1.0)
+    x0_ref = torch.as_tensor(fx["x0"])
+    cyc = (x_same.cpu() - x0_ref).abs()
     zc = z.cpu()
     slots = [int(s) for s in fx["z_sub_slots"]]
     zref = torch.as_tensor(fx["z_sub"])
@@ -87,11 +92,15 @@ def _run(cls, fx_name, res, ctx_dim, report):
                latent_maxabs=lat_err.max().item(), latent_rms=lat_err.pow(2).mean().sqrt().item(),
                latent_ref_rms=lat_ref.pow(2).mean().sqrt().item(), xT_maxabs=xT_err,
                eps_rel_slots=dict(zip([str(s) for s in slots if s > 0], eps_rel)), z_norm_rel=zn_rel,
+               cycle99_maxabs=cyc.max().item(), cycle99_rms=cyc.pow(2).mean().sqrt().item(),
                reference_cpu_seconds=float(fx["cpu_seconds"]))
     assert img.shape == (1, 3, res, res) and torch.isfinite(img).all()
     assert p >= PSNR_FLOOR, p
     assert zn_rel < 2e-3 * FMT, zn_rel
     assert max(eps_rel) < 5e-2 * FMT, eps_rel
+    # 99-step self-cycle at full size on a random-init 860 M-parameter network (the fp32 reference closes it to 1.6e-5,
+    # SURVEY.md 8c; a 16-bit engine re-quantises x_t every step)
+    assert cyc.max().item() < 0.15 * FMT, cyc.max().item()
     return p
 
 
