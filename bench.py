@@ -18,7 +18,8 @@ such launch sets running on R independent engines / HIP streams.
 
 Other BASELINE.json configurations: `--workload c3` (LDM text2img-large shapes, 256 x 256, batch 16) and
 `--workload c5r` (AFHQ improved-DDPM pair, 256 x 256, batch 4; REDUCED chain custom_steps 100 / es_steps 85 /
-refine_steps 10 = the reference cfg's 1000 / 850 / 100 divided by 10 - labelled as such in the line).
+refine_steps 10 = the reference cfg's 1000 / 850 / 100 divided by 10 - labelled as such in the line); `--workload c5`
+is the reference chain itself (1799 U-Net evaluations per image: use --steps 1..2).
 """
 import argparse
 import json
@@ -48,6 +49,12 @@ WORKLOADS = {
                metric="images/sec, LDM text2img-large 256px CycleDiffusion 100+100 steps (BASELINE config 3)",
                name="C3: LDM text2img-large-shaped U-Net (context 1280) + KL-f8 VAE, 256x256, custom_steps=99 "
                     "white_box_steps=100 eta=0.1 skip 0, 1 trial, encoder scale 1, decoder CFG 3"),
+    "c5": dict(cfg="experiments/bench_afhq_c5.cfg", res=256, batch=4, text=False,
+               flop_per_image=(849 + 850 + 100) * 387.9e9,   # 697.8 TFLOP
+               metric="images/sec, AFHQ cat->dog 256px, two improved-DDPM U-Nets, reference chain 1000 / 850 / 100 "
+                      "(BASELINE config 5)",
+               name="C5: two AFHQ improved-DDPM U-Nets (source / target), 256x256, sample_type ddim eta 0.1, "
+                    "custom_steps=1000 es_steps=850 refine_steps=100 (translate_afhqcat256_to_afhqdog256_ddim_eta01.cfg)"),
     "c5r": dict(cfg="experiments/bench_afhq_c5_reduced.cfg", res=256, batch=4, text=False,
                 flop_per_image=(84 + 85 + 10) * 387.9e9,
                 metric="images/sec, AFHQ cat->dog 256px, two improved-DDPM U-Nets, REDUCED chain (BASELINE config 5 / 10)",
@@ -155,7 +162,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=1,
                     help="launch sets in flight per GPU: independent engine replicas (own HIP stream, workspace and "
                          "weights) driven by host threads")
-    ap.add_argument("--precision", default="", help="c5r only: fp32 (default, the reference's arithmetic) or fp16")
+    ap.add_argument("--precision", default="", help="c5 / c5r only: fp32 (default, the reference's arithmetic) or fp16")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even at world size 1 (exercises the gather path on a 1-GPU box)")
     a = ap.parse_args()
@@ -186,7 +193,7 @@ def main():
     os.environ["CYCLEDIFF_SYNTHETIC_WEIGHTS"] = "1"  # no checkpoints in this tree: seeded synthetic weights (opt-in)
     args = get_config(wl["cfg"], config_root=os.path.join(ROOT, "config"))
     if a.precision:
-        assert a.workload == "c5r", "--precision applies to the pixel-space workload"
+        assert a.workload in ("c5", "c5r"), "--precision applies to the pixel-space workloads"
         args.gan.precision = a.precision
     # Engine replicas: replica r owns stream r, its own engine (workspace, split-K scratch) and weights. With the
     # default --coalesce 4 one replica already keeps 16 images in flight; more replicas only overlap kernel tails.

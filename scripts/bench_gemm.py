@@ -6,7 +6,8 @@ Appendix B, batch B' = 8 = the CFG decode pass of C2) and print TFLOP/s per shap
 import ctypes as C
 import sys
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cycle_diffusion_amd as cda
 from cycle_diffusion_amd._ffi import check
 
