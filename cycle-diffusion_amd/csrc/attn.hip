@@ -9,13 +9,27 @@
 //   S^T = K Q^T   via v_mfma_f32_32x32x16_bf16 with K as the A operand: every lane then owns ONE
 //                 query column (lane&31) and 16 of the tile's 32 keys, so the online-softmax row
 //                 statistics are per-lane registers plus one lane^32 exchange.
-//   O^T = V^T P^T with V pre-transposed in HBM ([B][H][D][T], keys contiguous) so the A operand is
-//                 two 8-byte LDS reads; P goes straight from the S accumulators to the B operand
-//                 (the k-slot permutation of the accumulator layout is applied to V^T's reads).
-// The loop is VALU-bound for small heads (d = 40: 160 MFMA flops per score against max + fma + exp2 +
-// convert), so the softmax works on raw scores (scale folded into the exp2 argument), masks only the
-// ragged last tile, packs P with one convert per pair and - where V^T has a spare padded row - gets
-// the row sums from the PV MFMA itself. fp32 softmax statistics and accumulation, 16-bit operands.
+//   O^T = V^T P^T P goes straight from the S accumulators to the B operand; the k-slot permutation of the
+//                 accumulator layout is applied to the reads of the A operand V^T. Two V layouts:
+//                 * token-major V ([B][T][ldv], as it leaves a fused q|k|v projection GEMM; VTOK = true): the tile
+//                   is staged [key][d] like K and the A fragments are gfx950 LDS transpose reads
+//                   (ds_read_b64_tr_b16: 16 lanes fetch a 4-key x 16-d block and each receives one d column), so
+//                   no V^T tensor and no transposing GEMM exist anywhere (round 2: the V^T = Wv.X^T GEMMs were
+//                   10 % of a step);
+//                 * V pre-transposed in HBM ([B][H][D][T], keys contiguous; VTOK = false), two 16-byte reads.
+// The loop is VALU-bound for small heads (d = 40: 160 MFMA flops per score; round-2 counters: 178 VALU
+// instructions / 846 VALU-busy cycles per 64-key tile and wave against 448 MFMA cycles), so the per-score VALU
+// work is cut to max + exp2 + convert:
+//   * Q arrives in log2 units (softmax scale * log2(e) folded into the packed to_q weights, or applied
+//     to the Q fragments once per workgroup), so a score needs no multiply;
+//   * the running reference maximum m is kept as a 16-register block of -m that is the C operand of the
+//     first QK^T MFMA: the accumulators come out as s - m and go straight into v_exp_f32;
+//   * deferred maximum: m is only moved (accumulators, row sums and the -m block rescaled) when some row
+//     of the wave exceeds it by more than 2^8 - a wave-uniform, rare branch; between moves probabilities
+//     lie in (0, 256], exact for the final o / l because numerator and denominator share m;
+//   * the ragged last tile alone is masked, P is packed with one convert per pair and - where V^T has a
+//     spare padded row - the row sums fall out of the PV MFMA itself.
+// fp32 softmax statistics and accumulation, 16-bit operands.
 #include "common.h"
 #include "kernels.h"
 
@@ -30,7 +44,7 @@ constexpr int KT = 64;  // keys per tile
 // probabilities the numerator uses) instead of 32 VALU adds per tile.
 // NBUF = 2: the next tile's K / V^T are fetched into registers before the current tile's math and
 // written to the other LDS buffer after it - one barrier per tile.
-template <int DQK, int DV, int DH, int NBUF>
+template <int DQK, int DV, int DH, int NBUF, bool VTOK>
 __global__ __launch_bounds__(256, DV <= 96 ? 2 : 1) void k_attention(AttnParams p) {
   constexpr int KLD = DQK + 8;  // elements per K row in LDS (16 B pad)
   constexpr int VLD = KT + 8;   // elements per V^T row in LDS
@@ -38,11 +52,16 @@ __global__ __launch_bounds__(256, DV <= 96 ? 2 : 1) void k_attention(AttnParams 
   constexpr int NDT = DV / 32;
   constexpr int CPR = DQK / 8;
   constexpr int NKR = (KT * CPR + 255) / 256;  // staging registers (uint4) per thread
-  constexpr int NVR = DV * 8 / 256;
   constexpr bool ONES = DH > 0;
+  // token-major V tile in LDS: [key][VS]; the row stride is 16 or 48 dwords mod 64, so the four key rows x 64 bytes
+  // that the 32 lanes of a transpose-read group touch fall on 64 distinct banks
+  constexpr int VS = DV <= 32 ? 32 : (DV <= 96 ? 96 : 160);
+  constexpr int CPRV = ONES ? DH / 8 + 1 : DV / 8;  // 16-byte chunks staged per key row (the last one: ones column)
+  constexpr int NVR = VTOK ? (KT * CPRV + 255) / 256 : DV * 8 / 256;
+  constexpr int VBUF = VTOK ? KT * VS : DV * VLD;
   static_assert(!ONES || (DH < DV && (DH & 7) == 0 && ((DH >> 2) & 1) == 0), "ones row placement");
   __shared__ __attribute__((aligned(16))) bf16_t Ks[NBUF][KT * KLD];
-  __shared__ __attribute__((aligned(16))) bf16_t Vs[NBUF][DV * VLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[NBUF][VBUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qi = lane & 31, half = lane >> 5;
@@ -52,10 +71,12 @@ __global__ __launch_bounds__(256, DV <= 96 ? 2 : 1) void k_attention(AttnParams 
 
   const bf16_t* qb = p.q + (int64_t)b * p.q_bs + h * D;
   const bf16_t* kb = p.k + (int64_t)b * p.k_bs + h * D;
-  const bf16_t* vtb = p.vt + ((int64_t)b * p.H + h) * (int64_t)p.vt_dpad * p.vt_tpad;
+  const bf16_t* vtb = VTOK ? p.v + (int64_t)b * p.v_bs + h * D
+                           : p.vt + ((int64_t)b * p.H + h) * (int64_t)p.vt_dpad * p.vt_tpad;
 
-  // Q fragments (B operand of S^T = K Q^T): lane holds Q[q][ks*16 + 8*half .. +7]
+  // Q fragments (B operand of S^T = K Q^T): lane holds Q[q][ks*16 + 8*half .. +7], in log2 score units
   bf16x8 qf[NKS];
+  const float qsc = p.scale * 1.44269504088896340736f;
   {
     const int q = q0 + qi;
 #pragma unroll
@@ -63,6 +84,13 @@ __global__ __launch_bounds__(256, DV <= 96 ? 2 : 1) void k_attention(AttnParams 
       const int d0 = ks * 16 + 8 * half;
       uint4 raw = make_uint4(0, 0, 0, 0);
       if (q < p.Tq && d0 < D) raw = *(const uint4*)(qb + (int64_t)q * p.ldq + d0);
+      if (!p.q_log2) {  // q not produced in log2 units: scale the fragment here (one extra 16-bit rounding)
+        float f[8];
+        unpack8(raw, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= qsc;
+        raw = pack8(f);
+      }
       qf[ks] = *(bf16x8*)&raw;
     }
   }
@@ -70,6 +98,7 @@ __global__ __launch_bounds__(256, DV <= 96 ? 2 : 1) void k_attention(AttnParams 
   // ---- staging plan (fixed per thread): K tile [64][DQK] zero padded, V^T tile [DV][64]
   int k_goff[NKR], k_loff[NKR], k_row[NKR];
   int v_loff[NVR], v_row[NVR];
+  bool v_ones[NVR];
   int64_t v_goff[NVR];
 #pragma unroll
   for (int i = 0; i < NKR; ++i) {
@@ -83,10 +112,20 @@ __global__ __launch_bounds__(256, DV <= 96 ? 2 : 1) void k_attention(AttnParams 
 #pragma unroll
   for (int i = 0; i < NVR; ++i) {
     const int id = tid + i * 256;
-    const int row = id >> 3, ch = id & 7;
-    v_row[i] = row;
-    v_goff[i] = (int64_t)row * p.vt_tpad + ch * 8;
-    v_loff[i] = row * VLD + ch * 8;
+    if (VTOK) {  // [key][d] like K: chunk ch of key row `row`; v_row = key row (or out of range), chunk CPRV-1 = ones
+      const int row = id / CPRV, ch = id % CPRV;
+      const bool data = id < KT * CPRV && ch * 8 < D;
+      v_row[i] = data ? row : (1 << 30);
+      v_goff[i] = (int64_t)row * p.ldv + ch * 8;
+      v_loff[i] = id < KT * CPRV ? row * VS + ch * 8 : -1;
+      v_ones[i] = ONES && ch * 8 == DH;
+    } else {
+      const int row = id >> 3, ch = id & 7;
+      v_row[i] = row;
+      v_goff[i] = (int64_t)row * p.vt_tpad + ch * 8;
+      v_loff[i] = row * VLD + (ch >> 1) * 16 + (ch & 1) * 4;
+      v_ones[i] = false;
+    }
   }
   uint4 kreg[NKR], vreg[NVR];
   auto fetch = [&](int key0) {
@@ -98,28 +137,48 @@ __global__ __launch_bounds__(256, DV <= 96 ? 2 : 1) void k_attention(AttnParams 
 #pragma unroll
     for (int i = 0; i < NVR; ++i) {
       vreg[i] = make_uint4(0, 0, 0, 0);
-      if (v_row[i] < p.vt_dpad) vreg[i] = *(const uint4*)(vtb + v_goff[i] + key0);
+      if (VTOK) {  // keys beyond Tk are zero rows (their probabilities are zero, 0 * garbage must not be NaN)
+        if (key0 + v_row[i] < p.Tk && v_row[i] < KT) vreg[i] = *(const uint4*)(vtb + (int64_t)key0 * p.ldv + v_goff[i]);
+      } else {
+        if (v_row[i] < p.vt_dpad) vreg[i] = *(const uint4*)(vtb + v_goff[i] + key0);
+      }
     }
   };
+  // VTOK = false: V^T rows are stored with the four 4-key pieces of every 16-key group in the order [0 2 1 3]: the
+  // two pieces a lane feeds to one PV MFMA (keys 4*half.. and 8+4*half.., the accumulator layout of S^T) are then one
+  // aligned 16-byte read (row stride 36 dwords: conflict-free ds_read_b128) instead of two 8-byte ones.
+  // The ones row / column is substituted here so the loads stay in flight during the math.
   auto commit = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NKR; ++i)
       if (k_loff[i] >= 0) *(uint4*)(&Ks[buf][k_loff[i]]) = kreg[i];
 #pragma unroll
     for (int i = 0; i < NVR; ++i) {
-      uint4 v = vreg[i];  // the ones row is substituted here so the loads stay in flight during the math
-      if (ONES && v_row[i] == DH) v = make_uint4(kOnePair, kOnePair, kOnePair, kOnePair);
-      *(uint4*)(&Vs[buf][v_loff[i]]) = v;
+      uint4 v = vreg[i];
+      if (VTOK) {
+        if (v_ones[i]) v = make_uint4(kOnePair & 0xffffu, 0, 0, 0);  // column DH = 1, the rest of the chunk 0
+        if (v_loff[i] >= 0) *(uint4*)(&Vs[buf][v_loff[i]]) = v;
+      } else {
+        if (ONES && v_row[i] == DH) v = make_uint4(kOnePair, kOnePair, kOnePair, kOnePair);
+        *(uint2*)(&Vs[buf][v_loff[i]]) = make_uint2(v.x, v.y);
+        *(uint2*)(&Vs[buf][v_loff[i] + 8]) = make_uint2(v.z, v.w);
+      }
     }
   };
+  // transpose-read geometry (VTOK): 16 lanes fetch the 4-key x 16-d block [4 * half + (i >> 2)][16 * g + 4 * (i & 3)..]
+  // (i = lane & 15, g = (lane >> 4) & 1) and lane l receives d column 16 * g + i = lane & 31 of its 4 keys
+  const int vtr_off = ((4 * half + ((lane & 15) >> 2)) * VS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
 
   f32x16 o[NDT];
 #pragma unroll
   for (int i = 0; i < NDT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-  float m_run = -INFINITY, l_part = 0.f;  // m_run in raw (unscaled) score units
-  const float sc = p.scale * 1.44269504088896340736f;  // fold log2(e): softmax via exp2
+  f32x16 negm;  // -m of this lane's query in every register: C operand of the first QK^T MFMA of a tile
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+  float l_part = 0.f;
+  constexpr float kDefer = 8.0f;  // log2 units: probabilities stay <= 2^8 between moves of m
 
   const int ntiles = (p.Tk + KT - 1) / KT;
   fetch(0);
@@ -133,19 +192,23 @@ __global__ __launch_bounds__(256, DV <= 96 ? 2 : 1) void k_attention(AttnParams 
     const bf16_t* Kt = Ks[buf];
     const bf16_t* Vt = Vs[buf];
 
-    // ---- S^T = K Q^T for the two 32-key halves of the tile
+    // ---- S^T - m = K Q^T - m for the two 32-key halves of the tile
     f32x16 s[2];
+    {
+      bf16x8 kf[2][NKS];  // all K fragments first: the LDS latency is paid once, not per MFMA
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
+      for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kh][r] = 0.f;
+        for (int ks = 0; ks < NKS; ++ks)
+          kf[kh][ks] = *(const bf16x8*)(Kt + (kh * 32 + qi) * KLD + ks * 16 + 8 * half);
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs (the scheduler re-serialises them)
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(Kt + (kh * 32 + qi) * KLD + ks * 16 + 8 * half);
-        s[kh] = CD_MFMA_32x32x16(kf, qf[ks], s[kh]);
-      }
+      for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)  // the two 32-key halves alternate: no back-to-back dependent MFMAs
+          s[kh] = CD_MFMA_32x32x16(kf[kh][ks], qf[ks], ks == 0 ? negm : s[kh]);
     }
-    // ---- keys beyond Tk (last tile only), running max in raw units
+    // ---- keys beyond Tk (last tile only) / causal mask
     if (key0 + KT > p.Tk || p.causal) {
       const int kmax = p.causal ? min(p.Tk - 1, q0 + qi) : p.Tk - 1;  // last visible key of this lane's query
 #pragma unroll
@@ -156,35 +219,46 @@ __global__ __launch_bounds__(256, DV <= 96 ? 2 : 1) void k_attention(AttnParams 
           s[kh][r] = key <= kmax ? s[kh][r] : -INFINITY;
         }
     }
-    // v_max3 directly: fmaxf() would first canonicalise every MFMA result (one extra VALU op each)
-    float mx = s[0][0];
+    // tile maximum relative to m. v_max3 directly: fmaxf() would first canonicalise every MFMA result
+    float mx;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(s[0][0]), "v"(s[1][0]), "v"(s[0][1]));
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[1][1]), "v"(s[0][2]));
 #pragma unroll
     for (int r = 3; r < 16; ++r)
       asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[1][r - 1]), "v"(s[0][r]));
     asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(s[1][15]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc);  // first tile: exp2(-inf) = 0
-    m_run = m_new;
-    const float mneg = -m_new * sc;
+    // ---- move m (rare, wave-uniform): always on the first tile, later only if a row grew past 2^kDefer.
+    // Textbook order: the decision precedes the exponentiation of the tile it covers, and everything
+    // accumulated against the old m (o, the row sums inside o or l_part) is rescaled exactly once.
+    if (t == 0 || __any(mx > kDefer)) {
+      const float mxq = fmaxf(mx, __shfl_xor(mx, 32));  // both half-lanes of a query agree
+      float delta = t == 0 ? mxq : fmaxf(mxq, 0.f);
+      delta = delta == -INFINITY ? 0.f : delta;
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kh][r] -= delta;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negm[r] -= delta;
+#pragma unroll
+      for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      l_part *= alpha;
+    }
     uint32_t pw[2][8];
     float ps = 0.f;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kh][r], sc, mneg));
-        const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kh][r + 1], sc, mneg));
+        const float e0 = __builtin_amdgcn_exp2f(s[kh][r]);
+        const float e1 = __builtin_amdgcn_exp2f(s[kh][r + 1]);
         if (!ONES) ps += e0 + e1;
-        pw[kh][r >> 1] = pack2_unit(e0, e1);
+        pw[kh][r >> 1] = pack2_prob(e0, e1);
       }
-    if (!ONES) l_part = l_part * alpha + ps;
-#pragma unroll
-    for (int i = 0; i < NDT; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    if (!ONES) l_part += ps;
 
     // ---- O^T += V^T P^T
 #pragma unroll
@@ -193,13 +267,19 @@ __global__ __launch_bounds__(256, DV <= 96 ? 2 : 1) void k_attention(AttnParams 
       for (int s2 = 0; s2 < 2; ++s2) {
         const uint4 praw = make_uint4(pw[kh][4 * s2], pw[kh][4 * s2 + 1], pw[kh][4 * s2 + 2], pw[kh][4 * s2 + 3]);
         const bf16x8 pf = __builtin_bit_cast(bf16x8, praw);
-        const int kbase = kh * 32 + 16 * s2 + 4 * half;
+        const int kbase = kh * 32 + 16 * s2 + 8 * half;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
-          const bf16_t* vr = Vt + (dt * 32 + qi) * VLD + kbase;
-          const uint2 lo = *(const uint2*)(vr);
-          const uint2 hi = *(const uint2*)(vr + 8);
-          const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+          bf16x8 vf;
+          if (VTOK) {
+            typedef __attribute__((address_space(3))) bf16x4* lds4_t;
+            const bf16_t* vr = Vt + vtr_off + (kh * 32 + 16 * s2) * VS + dt * 32;
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)vr);
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vr + 8 * VS));
+            vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          } else {
+            vf = *(const bf16x8*)(Vt + (dt * 32 + qi) * VLD + kbase);
+          }
           o[dt] = CD_MFMA_32x32x16(vf, pf, o[dt]);
         }
       }
@@ -274,11 +354,16 @@ __global__ __launch_bounds__(256) void k_transpose_v(const bf16_t* __restrict__ 
 
 void launch_attention(hipStream_t st, const AttnParams& p) {
   CD_CHECK(p.D % 8 == 0 && p.D <= 160, "attention: head dim %d unsupported by the fused kernel", p.D);
-  CD_CHECK(p.vt_tpad % KT == 0 && p.vt_tpad >= round_up(p.Tk, KT), "attention: V^T key padding");
+  CD_CHECK((p.v != nullptr) != (p.vt != nullptr), "attention: exactly one of v (token-major) / vt (transposed)");
+  if (p.vt) CD_CHECK(p.vt_tpad % KT == 0 && p.vt_tpad >= round_up(p.Tk, KT), "attention: V^T key padding");
+  else CD_CHECK((p.ldv % 8) == 0 && ((uintptr_t)p.v & 15) == 0, "attention: V row stride / alignment");
   CD_CHECK((p.ldq % 8) == 0 && (p.ldk % 8) == 0 && (p.ldo % 4) == 0, "attention: leading dims");
   dim3 grid(ceil_div(p.Tq, 128), p.H, p.B);
-#define CD_ATTN(DQK, DV, DH, NBUF) \
-  hipLaunchKernelGGL((k_attention<DQK, DV, DH, NBUF>), grid, dim3(256), 0, st, p)
+#define CD_ATTN(DQK, DV, DH, NBUF)                                                                       \
+  do {                                                                                                   \
+    if (p.v) hipLaunchKernelGGL((k_attention<DQK, DV, DH, NBUF, true>), grid, dim3(256), 0, st, p);       \
+    else hipLaunchKernelGGL((k_attention<DQK, DV, DH, NBUF, false>), grid, dim3(256), 0, st, p);          \
+  } while (0)
   if (p.D == 40) CD_ATTN(48, 64, 40, 2);       // SD / LDM 320-channel level
   else if (p.D == 80) CD_ATTN(80, 96, 80, 2);  // 640-channel level
   else if (p.D <= 32) CD_ATTN(32, 32, 0, 2);

@@ -78,14 +78,17 @@ __device__ inline void unpack8(const uint4& raw, float* f) {
 __device__ inline uint32_t pack2(float lo, float hi) {
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
-// two values known to lie in [0, 1] (softmax probabilities): no saturation needed
-__device__ inline uint32_t pack2_unit(float lo, float hi) {
+// two softmax probabilities, known to lie in [0, 2^8] (deferred-maximum attention): one hardware convert, no
+// saturation needed
+__device__ inline uint32_t pack2_prob(float lo, float hi) {
 #if CD_ACT_FP16
   typedef __attribute__((ext_vector_type(2))) _Float16 h2;
   const h2 v = {(_Float16)lo, (_Float16)hi};
   return __builtin_bit_cast(uint32_t, v);
 #else
-  return pack2(lo, hi);
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
 #endif
 }
 #if CD_ACT_FP16

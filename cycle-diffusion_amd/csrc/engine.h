@@ -65,6 +65,7 @@ struct PackTarget {
   int dst_off = 0, K = 1;
   bool geglu = false;
   int geglu_N = 0;
+  float scale = 1.f;  // rows are multiplied by this before the one rounding to the packed format
 };
 
 struct ParamDecl {
@@ -85,12 +86,13 @@ class ParamStore {
   // declare reference tensors and where their rows go
   ParamDecl& declare(const std::string& name, std::vector<int64_t> shape);
   // whole tensor -> whole ConvW; ref_ndim = rank of the reference tensor (2 Linear, 3 Conv1d, 4 Conv2d; 0 = auto)
-  void conv_weight(const std::string& name, ConvW* c, int ref_ndim = 0);
+  // scale: folded into the rows before they are rounded (attention: softmax scale * log2(e) into to_q)
+  void conv_weight(const std::string& name, ConvW* c, int ref_ndim = 0, float scale = 1.f);
   // reference tensor of shape [Cin][N] applied as `x @ W` (OpenAI CLIP `proj` / `text_projection`)
   void conv_weight_t(const std::string& name, ConvW* c);
   void conv_bias(const std::string& name, ConvW* c);
   void conv_rows(const std::string& name, std::vector<int64_t> shape, ConvW* c, int dst_row0, int rows,
-                 int src_base, int grp, int grp_stride);
+                 int src_base, int grp, int grp_stride, float scale = 1.f);
   void bias_rows(const std::string& name, int64_t n_total, float* dst, int dst_off, int rows, int src_base,
                  int grp, int grp_stride);
   void vec(const std::string& name, float* dst, int n);
@@ -155,8 +157,9 @@ Act upsample2_fwd(Ctx& c, const Act& x);
 Act attention_f32_fwd(Ctx& c, const Act& qk, const Act& v, int H, int D, float scale, const float* obias);
 
 // multi-head attention on token-major activations; vt is [B][H*D][Tpad]
+// q_log2: q already carries scale * log2(e) (folded into its projection weights); `scale` is then unused
 Act attention_fwd(Ctx& c, const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* vt, int B,
-                  int H, int Tq, int Tk, int Tpad, int D, float scale, int Himg, int Wimg);
+                  int H, int Tq, int Tk, int Tpad, int D, float scale, int Himg, int Wimg, bool q_log2 = false);
 
 // ------------------------------------------------------------------ networks
 class Net {

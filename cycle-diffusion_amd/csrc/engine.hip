@@ -65,7 +65,7 @@ ParamDecl& ParamStore::declare(const std::string& name, std::vector<int64_t> sha
   by_name_[name] = d;
   return *d;
 }
-void ParamStore::conv_weight(const std::string& name, ConvW* c, int ref_ndim) {
+void ParamStore::conv_weight(const std::string& name, ConvW* c, int ref_ndim, float scale) {
   std::vector<int64_t> shape;
   if (ref_ndim == 0) ref_ndim = (c->KH == 1 && c->KW == 1) ? 2 : 4;
   if (ref_ndim == 2) shape = {c->N, c->Cin};
@@ -73,7 +73,7 @@ void ParamStore::conv_weight(const std::string& name, ConvW* c, int ref_ndim) {
   else shape = {c->N, c->Cin, c->KH, c->KW};
   ParamDecl& d = declare(name, shape);
   PackTarget t; t.kind = PackTarget::MATRIX_BF16; t.conv = c; t.dst_row0 = 0; t.rows = c->N;
-  t.src_base = 0; t.grp = c->N; t.grp_stride = 0; t.geglu = c->geglu;
+  t.src_base = 0; t.grp = c->N; t.grp_stride = 0; t.geglu = c->geglu; t.scale = scale;
   d.targets.push_back(t);
 }
 void ParamStore::conv_weight_t(const std::string& name, ConvW* c) {
@@ -92,10 +92,10 @@ void ParamStore::conv_bias(const std::string& name, ConvW* c) {
   d.targets.push_back(t);
 }
 void ParamStore::conv_rows(const std::string& name, std::vector<int64_t> shape, ConvW* c, int dst_row0,
-                           int rows, int src_base, int grp, int grp_stride) {
+                           int rows, int src_base, int grp, int grp_stride, float scale) {
   ParamDecl& d = declare(name, std::move(shape));
   PackTarget t; t.kind = PackTarget::MATRIX_BF16; t.conv = c; t.dst_row0 = dst_row0; t.rows = rows;
-  t.src_base = src_base; t.grp = grp; t.grp_stride = grp_stride;
+  t.src_base = src_base; t.grp = grp; t.grp_stride = grp_stride; t.scale = scale;
   d.targets.push_back(t);
 }
 void ParamStore::bias_rows(const std::string& name, int64_t n_total, float* dst, int dst_off, int rows,
@@ -119,7 +119,7 @@ void ParamStore::mat_f32(const std::string& name, float* dst, int N, int K, int 
 template <typename OutT>
 __global__ void k_pack_rows(const float* __restrict__ w, OutT* __restrict__ out, int rows, int Cin,
                             int KH, int KW, int Cpad, int dst_row0, int src_base, int grp,
-                            int grp_stride, int geglu, int Ntot) {
+                            int grp_stride, int geglu, int Ntot, float scale) {
   const int64_t total = (int64_t)rows * KH * KW * Cpad;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -135,7 +135,7 @@ __global__ void k_pack_rows(const float* __restrict__ w, OutT* __restrict__ out,
     }
     const int src = src_base + (jj / grp) * grp_stride + (jj % grp);
     float v = 0.f;
-    if (c < Cin) v = w[(((int64_t)src * Cin + c) * KH + r) * KW + s];
+    if (c < Cin) v = w[(((int64_t)src * Cin + c) * KH + r) * KW + s] * scale;
     const int64_t o = ((int64_t)(dst_row0 + j) * KH * KW + (int64_t)r * KW + s) * Cpad + c;
     if constexpr (sizeof(OutT) == 4) out[o] = v;
     else out[o] = f2bf(v);
@@ -179,10 +179,11 @@ void ParamStore::load(hipStream_t st, const std::string& name, const float* host
       if (grid > 8192) grid = 8192;
       if (c->f32)
         hipLaunchKernelGGL(k_pack_rows<float>, dim3(grid), dim3(256), 0, st, staging_, (float*)c->w, t.rows, c->Cin,
-                           c->KH, c->KW, c->Cpad, t.dst_row0, t.src_base, t.grp, t.grp_stride, t.geglu ? 1 : 0, c->N);
+                           c->KH, c->KW, c->Cpad, t.dst_row0, t.src_base, t.grp, t.grp_stride, t.geglu ? 1 : 0, c->N,
+                           t.scale);
       else
         hipLaunchKernelGGL(k_pack_rows<bf16_t>, dim3(grid), dim3(256), 0, st, staging_, c->w, t.rows, c->Cin, c->KH,
-                           c->KW, c->Cpad, t.dst_row0, t.src_base, t.grp, t.grp_stride, t.geglu ? 1 : 0, c->N);
+                           c->KW, c->Cpad, t.dst_row0, t.src_base, t.grp, t.grp_stride, t.geglu ? 1 : 0, c->N, t.scale);
     } else {
       // small: map on the host
       const int K = (t.kind == PackTarget::MATRIX_F32) ? t.K : 1;
@@ -341,7 +342,7 @@ Act layernorm_fwd(Ctx& c, const LNW& w, const Act& x) {
 }
 
 Act attention_fwd(Ctx& c, const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* vt, int B,
-                  int H, int Tq, int Tk, int Tpad, int D, float scale, int Himg, int Wimg) {
+                  int H, int Tq, int Tk, int Tpad, int D, float scale, int Himg, int Wimg, bool q_log2) {
   CD_CHECK(!c.f32, "attention: 16-bit kernel called on the fp32 path");
   Act o = alloc_act(c, B, Himg, Wimg, H * D);
   AttnParams p;
@@ -350,7 +351,7 @@ Act attention_fwd(Ctx& c, const bf16_t* q, int ldq, const bf16_t* k, int ldk, co
   p.ldq = ldq; p.ldk = ldk; p.ldo = o.ld;
   p.q_bs = (int64_t)Tq * ldq; p.k_bs = (int64_t)Tk * ldk; p.o_bs = (int64_t)Tq * o.ld;
   p.vt_dpad = D; p.vt_tpad = Tpad;
-  p.scale = scale;
+  p.scale = scale; p.q_log2 = q_log2 ? 1 : 0;
   launch_attention(c.st, p);
   return o;
 }

@@ -164,13 +164,17 @@ void launch_softmax_rows(hipStream_t st, const float* s, int lds, bf16_t* p, int
 struct AttnParams {
   const bf16_t* q = nullptr;   // [B][Tq][ldq], head h at column h*D
   const bf16_t* k = nullptr;   // [B][Tk][ldk]
-  const bf16_t* vt = nullptr;  // V transposed: [B][H][Dv_pad][Tk_pad]  (keys contiguous)
+  // values, exactly one of:
+  const bf16_t* v = nullptr;   //   token-major [B][Tk][ldv], head h at column h*D (fused q|k|v projection output)
+  const bf16_t* vt = nullptr;  //   transposed: [B][H][Dv_pad][Tk_pad]  (keys contiguous)
+  int ldv = 0; int64_t v_bs = 0;
   bf16_t* o = nullptr;         // [B][Tq][ldo]
   int B = 0, H = 0, Tq = 0, Tk = 0, D = 0;
   int ldq = 0, ldk = 0, ldo = 0;
   int64_t q_bs = 0, k_bs = 0, o_bs = 0;
   int vt_dpad = 0, vt_tpad = 0;
-  float scale = 1.0f;
+  float scale = 1.0f;            // softmax scale; ignored when q_log2 is set
+  int q_log2 = 0;                // 1: q already carries scale * log2(e) (folded into the packed to_q weights)
   const float* obias = nullptr;  // [H*D] added to the output (value-projection bias: rows of P sum to 1)
   int causal = 0;                // 1: key j is visible to query i only if j <= i (CLIP text transformer)
 };

@@ -226,50 +226,78 @@ __global__ __launch_bounds__(256) void k_gn_apply(GroupNormParams p, int rows_pe
   }
 }
 
-// one wave per row; C multiple of 8, C <= 2048
+// One wave per row, R rows per wave; C multiple of 8, C <= 64 * 8 * VPL. All 16-byte loads of the wave's R rows are
+// issued before any arithmetic: a single 640-byte row per wave (C = 320) keeps only ~5 MB in flight over the whole
+// chip, a third of what HBM latency x bandwidth needs; R = 4 puts the pass at the speed of the other streaming
+// kernels. Per-row arithmetic and reduction order are those of the one-row form (results are bit-identical).
+template <int VPL, int R>
 __global__ __launch_bounds__(256) void k_layernorm(const bf16_t* __restrict__ x, int ldx,
                                                    bf16_t* __restrict__ y, int ldy, int rows, int C,
                                                    const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, float eps) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= rows) return;
   const int nvec = C >> 3;
-  float f[4][8];
-  float s = 0.f;
+  uint4 raw[R][VPL];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int v = lane + j * 64;
-    if (v < nvec) {
-      unpack8(*(const uint4*)(x + (int64_t)row * ldx + v * 8), f[j]);
+  for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += f[j][e];
+    for (int j = 0; j < VPL; ++j) {
+      // unconditional loads (clamped to a valid row / vector; the duplicates are never used): predicated ones
+      // end up behind branches with a vmcnt(0) between them
+      const int v = lane + j * 64 < nvec ? lane + j * 64 : 0;
+      const int row = row0 + r < rows ? row0 + r : rows - 1;
+      raw[r][j] = *(const uint4*)(x + (int64_t)row * ldx + v * 8);
+    }
+  float ga[VPL][8], be[VPL][8];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int v = lane + j * 64 < nvec ? lane + j * 64 : 0;
+    {
+      const f32x4 g0 = *(const f32x4*)(gamma + v * 8), g1 = *(const f32x4*)(gamma + v * 8 + 4);
+      const f32x4 b0 = *(const f32x4*)(beta + v * 8), b1 = *(const f32x4*)(beta + v * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ga[j][e] = g0[e]; ga[j][4 + e] = g1[e]; be[j][e] = b0[e]; be[j][4 + e] = b1[e]; }
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  const float mean = s / (float)C;
-  float q = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const int row = row0 + r;
+    if (row >= rows) break;  // wave-uniform
+    float f[VPL][8];
+    float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int v = lane + j * 64;
-    if (v < nvec) {
+    for (int j = 0; j < VPL; ++j) {
+      unpack8(raw[r][j], f[j]);
+      if (lane + j * 64 < nvec) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = f[j][e] - mean; q += d * d; }
+        for (int e = 0; e < 8; ++e) s += f[j][e];
+      }
     }
-  }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-  const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int v = lane + j * 64;
-    if (v < nvec) {
-      float o8[8];
+    for (int j = 0; j < VPL; ++j) {
+      if (lane + j * 64 < nvec) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        o8[e] = (f[j][e] - mean) * rstd * gamma[v * 8 + e] + beta[v * 8 + e];
-      *(uint4*)(y + (int64_t)row * ldy + v * 8) = pack8(o8);
+        for (int e = 0; e < 8; ++e) { const float d = f[j][e] - mean; q += d * d; }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const int v = lane + j * 64;
+      if (v < nvec) {
+        float o8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = (f[j][e] - mean) * rstd * ga[j][e] + be[j][e];
+        *(uint4*)(y + (int64_t)row * ldy + v * 8) = pack8(o8);
+      }
     }
   }
 }
@@ -344,8 +372,15 @@ void launch_groupnorm(hipStream_t st, const GroupNormParams& p) {
 void launch_layernorm(hipStream_t st, const bf16_t* x, int ldx, bf16_t* y, int ldy, int rows,
                       int C, const float* gamma, const float* beta, float eps) {
   CD_CHECK(C % 8 == 0 && C <= 2048, "layernorm: C=%d unsupported", C);
-  hipLaunchKernelGGL(k_layernorm, dim3(ceil_div(rows, 4)), dim3(256), 0, st, x, ldx, y, ldy, rows,
-                     C, gamma, beta, eps);
+  CD_CHECK((ldx & 7) == 0 && (ldy & 7) == 0, "layernorm: row strides must be multiples of 8 elements");
+#define CD_LN(VPL, R)                                                                                              \
+  hipLaunchKernelGGL((k_layernorm<VPL, R>), dim3(ceil_div(rows, 4 * R)), dim3(256), 0, st, x, ldx, y, ldy, rows, C, \
+                     gamma, beta, eps)
+  if (C <= 512) CD_LN(1, 4);
+  else if (C <= 1024) CD_LN(2, 4);
+  else if (C <= 1536) CD_LN(3, 2);
+  else CD_LN(4, 2);
+#undef CD_LN
 }
 
 void launch_softmax_rows(hipStream_t st, const float* s, int lds_, bf16_t* p, int ldp, int64_t rows,

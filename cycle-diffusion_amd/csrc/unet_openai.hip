@@ -97,9 +97,10 @@ LNW make_ln(ParamStore& ps, const std::string& pfx, int C) {
 }
 // ref_ndim: rank of the reference weight tensor (2 = nn.Linear, 3 = Conv1d, 4 = Conv2d)
 ConvW* make_conv(ParamStore& ps, const std::string& pfx, int N, int Cin, int k, bool bias, bool geglu = false,
-                 int ref_ndim = 4) {
+                 int ref_ndim = 4, float wscale = 1.f) {
+  CD_CHECK(!(bias && wscale != 1.f), "a folded weight scale needs the bias scaled too");
   ConvW* c = ps.new_conv(N, Cin, k, k, bias, geglu);
-  ps.conv_weight(pfx + ".weight", c, ref_ndim);
+  ps.conv_weight(pfx + ".weight", c, ref_ndim, wscale);
   if (bias) ps.conv_bias(pfx + ".bias", c);
   return c;
 }
@@ -129,13 +130,16 @@ int UNetOpenAI::add_st(const std::string& pfx, int C, int heads, int dh) {
   s.ln1 = make_ln(params, tb + ".norm1", C);
   s.ln2 = make_ln(params, tb + ".norm2", C);
   s.ln3 = make_ln(params, tb + ".norm3", C);
-  // self-attention: fused [Wq;Wk] GEMM, Wv kept as an A-operand matrix for the V^T GEMM
+  // self-attention: fused [Wq;Wk] GEMM, Wv kept as an A-operand matrix for the V^T GEMM.
+  // to_q rows carry the softmax scale and log2(e) (attention.py:178: sim = q k^T * dim_head^-0.5), folded in
+  // fp32 before the one rounding to 16 bits: q comes out of its GEMM in the log2 units k_attention consumes.
+  const float qscale = 1.44269504088896340736f / sqrtf((float)dh);
   s.qk1 = params.new_conv(2 * C, C, 1, 1, false);
-  params.conv_rows(tb + ".attn1.to_q.weight", {C, C}, s.qk1, 0, C, 0, C, 0);
+  params.conv_rows(tb + ".attn1.to_q.weight", {C, C}, s.qk1, 0, C, 0, C, 0, qscale);
   params.conv_rows(tb + ".attn1.to_k.weight", {C, C}, s.qk1, C, C, 0, C, 0);
   s.v1 = make_conv(params, tb + ".attn1.to_v", C, C, 1, false, false, 2);
   s.o1 = make_conv(params, tb + ".attn1.to_out.0", C, C, 1, true, false, 2);
-  s.q2 = make_conv(params, tb + ".attn2.to_q", C, C, 1, false, false, 2);
+  s.q2 = make_conv(params, tb + ".attn2.to_q", C, C, 1, false, false, 2, qscale);
   s.k2 = make_conv(params, tb + ".attn2.to_k", C, s.ctx, 1, false, false, 2);
   s.v2 = make_conv(params, tb + ".attn2.to_v", C, s.ctx, 1, false, false, 2);
   s.o2 = make_conv(params, tb + ".attn2.to_out.0", C, C, 1, true, false, 2);
@@ -379,7 +383,8 @@ Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x) {
     bf16_t* vt = (bf16_t*)c.arena->alloc((size_t)B * C * Tpad * 2);
     if (Tpad != T) HIP_CHECK(hipMemsetAsync(vt, 0, (size_t)B * C * Tpad * 2, c.st));
     vt_gemm(c, *s.v1, n1.p, n1.ld, B, T, Tpad, vt);
-    Act a = attention_fwd(c, qk.p, qk.ld, qk.p + C, qk.ld, vt, B, s.heads, T, T, Tpad, s.dh, scale, x.H, x.W);
+    Act a = attention_fwd(c, qk.p, qk.ld, qk.p + C, qk.ld, vt, B, s.heads, T, T, Tpad, s.dh, scale, x.H, x.W,
+                          /*q_log2=*/true);
     ConvOpts o; o.pad = 0; o.resid = &h; o.out = h.p; o.out_ld = h.ld;  // in-place residual update:
     conv_fwd(c, *s.o1, a, nullptr, o);  // each element is read then written by the same lane
     c.arena->release(m2);
@@ -388,7 +393,8 @@ Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x) {
     const size_t m2 = c.arena->mark();
     Act n2 = layernorm_fwd(c, s.ln2, h);
     Act q = conv_fwd(c, *s.q2, n2, nullptr, p0);
-    Act a = attention_fwd(c, q.p, q.ld, s.k2c, C, s.vt2c, B, s.heads, T, ctx_L_, ctx_Tpad_, s.dh, scale, x.H, x.W);
+    Act a = attention_fwd(c, q.p, q.ld, s.k2c, C, s.vt2c, B, s.heads, T, ctx_L_, ctx_Tpad_, s.dh, scale, x.H, x.W,
+                          /*q_log2=*/true);
     ConvOpts o; o.pad = 0; o.resid = &h; o.out = h.p; o.out_ld = h.ld;  // in-place residual update
     conv_fwd(c, *s.o2, a, nullptr, o);
     c.arena->release(m2);

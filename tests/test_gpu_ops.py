@@ -176,10 +176,11 @@ def test_groupnorm(engine, report, case):
     _check(report, "groupnorm/" + name, got, ref, rel=1.5e-2, mean=4e-3)
 
 
-@pytest.mark.parametrize("C", [320, 640, 1280, 64])
-def test_layernorm(engine, report, C):
+@pytest.mark.parametrize("C,rows", [(320, 300), (640, 301), (1280, 297), (64, 3), (768, 77), (2048, 35)])
+def test_layernorm(engine, report, C, rows):
+    # rows: not multiples of the 16 / 8 rows a workgroup covers (4 waves x 4 or 2 rows); C: 1 - 4 vectors per lane
     g = torch.Generator().manual_seed(13)
-    x = r16(torch.randn(300, C, generator=g) * 1.5 + 0.3)
+    x = r16(torch.randn(rows, C, generator=g) * 1.5 + 0.3)
     gamma = 1.0 + 0.2 * torch.randn(C, generator=g)
     beta = 0.2 * torch.randn(C, generator=g)
     ref = F.layer_norm(x, (C,), gamma, beta, 1e-5)
@@ -208,6 +209,37 @@ def test_attention(engine, report, case):
     ref = (att @ vh).transpose(1, 2).reshape(B, Tq, C)
     got = _ops.attention(engine, q, k, v, H, scale)
     _check(report, "attention/" + name, got, ref, rel=2e-2, mean=1e-2)
+
+
+@pytest.mark.parametrize("case", ["wide", "spike", "cross_spike"])
+def test_attention_deferred_max(engine, report, case):
+    """The attention kernel keeps a stale reference maximum and only moves it when a row's scores outgrow it by 2^8
+    (attn.hip). The move is a rare, data-dependent branch: bounded random scores never take it after the first
+    tile, so these inputs force it - a wide score distribution (log2-unit std ~6: the maximum of almost every row
+    grows past the threshold several times over 16 tiles) and single spiked keys late in the sequence, placed so
+    that some rows of a 32-query wave move their maximum while their neighbours do not."""
+    g = torch.Generator().manual_seed(23)
+    B, H, D = 1, 2, 40
+    Tq, Tk = (512, 1024) if case != "cross_spike" else (256, 77)
+    C = H * D
+    amp = 2.0 if case == "wide" else 1.0
+    q = torch.randn(B, Tq, C, generator=g) * amp
+    k = torch.randn(B, Tk, C, generator=g) * amp
+    v = torch.randn(B, Tk, C, generator=g)
+    if case != "wide":
+        for qrow, krow, gain in ((5, Tk - 3, 9.0), (37, Tk // 2 + 1, 14.0), (200, 70, 11.0)):
+            for h in range(H):
+                d = q[0, qrow, h * D:(h + 1) * D]
+                k[0, krow, h * D:(h + 1) * D] = d / d.norm() * gain * (h + 1)
+    q, k, v = r16(q), r16(k), r16(v)
+    scale = D ** -0.5
+    qh = q.view(B, Tq, H, D).transpose(1, 2).double()
+    kh = k.view(B, Tk, H, D).transpose(1, 2).double()
+    vh = v.view(B, Tk, H, D).transpose(1, 2).double()
+    att = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1)
+    ref = (att @ vh).transpose(1, 2).reshape(B, Tq, C).float()
+    got = _ops.attention(engine, q, k, v, H, scale)
+    _check(report, "attention_deferred_max/" + case, got, ref, rel=2e-2, mean=1e-2)
 
 
 def test_softmax_rows(engine, report):
