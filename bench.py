@@ -11,10 +11,11 @@ forward = wrapper.encode (VAE encode + DPM-Encoder) + wrapper.forward (coupled d
 i.e. exactly what Trainer.prediction_step times in the reference (trainer/trainer.py:788-789), followed
 by the per-step output gather (trainer.py:833). Prints ONE JSON line on rank 0.
 
-Steps are issued `--coalesce` at a time (default 4): the engine folds the queued batches into ONE launch set
-(16 images through the DPM-Encoder, 32 rows through the CFG decode), so every GEMM sees 4x the rows with one copy
-of the weights; each step still gets its own all-gather, in step order. `--in-flight R` additionally keeps R
-such launch sets running on R independent engines / HIP streams.
+Steps are issued `--coalesce` at a time (default: 8 for C2, 4 otherwise): the engine folds the queued batches into
+ONE launch set (C2: 32 images through the DPM-Encoder, 64 rows through the CFG decode), so every GEMM sees 8x the
+rows with one copy of the weights; each step still gets its own all-gather, in step order. `--coalesce 4` / `1` are
+the round-2a / round-1 operating points (measured beside the default, profiles/). `--in-flight R` additionally
+keeps R such launch sets running on R independent engines / HIP streams.
 
 Other BASELINE.json configurations: `--workload c3` (LDM text2img-large shapes, 256 x 256, batch 16) and
 `--workload c5r` (AFHQ improved-DDPM pair, 256 x 256, batch 4; REDUCED chain custom_steps 100 / es_steps 85 /
@@ -40,7 +41,7 @@ PEAK_TFLOPS = 2500.0  # dense 16-bit MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3  # fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
 
 WORKLOADS = {
-    "c2": dict(cfg="experiments/bench_sd_c2.cfg", res=512, batch=4, text=True, flop_per_image=F_IMG,
+    "c2": dict(cfg="experiments/bench_sd_c2.cfg", res=512, batch=4, text=True, flop_per_image=F_IMG, coalesce=8,
                metric="images/sec, SD-v1.4 512px CycleDiffusion 100+100 steps, 1/2/4/8 MI355X",
                name="C2: Stable-Diffusion-v1.4-shaped U-Net + KL-f8 VAE, 512x512, custom_steps=99 "
                     "white_box_steps=100 eta=0.1 skip 0, 1 trial, encoder scale 1, decoder CFG 3"),
@@ -134,10 +135,10 @@ def cpu_baseline(eng, un, vn, seed=0):
 
 def pmc_traffic_per_launch():
     """HBM-side bytes per k_conv_gemm launch from the committed rocprofv3 PMC passes (profiles/README.md):
-    FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over the U-Net forwards of one coalesced C2 launch set (B'=16
-    encode, B'=32 CFG decode), which launch equally often. None when the summaries are absent."""
+    FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over the U-Net forwards of one coalesced C2 launch set (B'=32
+    encode, B'=64 CFG decode), which launch equally often. None when the summaries are absent."""
     vals = []
-    for name in ("r2_conv_gemm_traffic_unet_b16.json", "r2_conv_gemm_traffic_unet_b32.json"):
+    for name in ("r2b_conv_gemm_traffic_unet_b32.json", "r2b_conv_gemm_traffic_unet_b64.json"):
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(path) as fh:
@@ -156,9 +157,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="image triplets per GPU per step (default: the workload's "
                     "BASELINE batch: 4 for C2, README.md:153; 16 for C3, README.md:195)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--coalesce", type=int, default=4,
+    ap.add_argument("--coalesce", type=int, default=0,
                     help="steps folded into one engine launch set (same images in flight as that many replicas, ONE "
-                         "copy of the weights, 4x the rows per GEMM); 1 = one launch set per step")
+                         "copy of the weights, that many times the rows per GEMM); 1 = one launch set per step; "
+                         "0 = the workload's default (8 for c2, 4 otherwise)")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="launch sets in flight per GPU: independent engine replicas (own HIP stream, workspace and "
                          "weights) driven by host threads")
@@ -196,9 +198,9 @@ def main():
         assert a.workload in ("c5", "c5r"), "--precision applies to the pixel-space workloads"
         args.gan.precision = a.precision
     # Engine replicas: replica r owns stream r, its own engine (workspace, split-K scratch) and weights. With the
-    # default --coalesce 4 one replica already keeps 16 images in flight; more replicas only overlap kernel tails.
+    # default coalescing one replica already keeps 32 images in flight (C2); more replicas only overlap kernel tails.
     n_rep = max(1, a.in_flight)
-    C = max(1, a.coalesce)
+    C = a.coalesce if a.coalesce > 0 else wl.get("coalesce", 4)
     os.environ["CYCLEDIFF_SHARE_SYNTH"] = "1" if n_rep > 1 else "0"  # generate the synthetic weights once per rank
     replicas = []
     for r in range(n_rep):

@@ -584,22 +584,26 @@ int cd_op_attention(cd_handle h, const float* q, const float* k, const float* v,
   CD_API_BEGIN
   enter_engine(h);
   CD_CHECK(h && q && k && v && o, "bad argument");
-  (void)use_transpose_kernel;
   ArenaScope arena_scope(h->arena);
   const int C = H * D, Tpad = round_up(Tk, 64);
   bf16_t* qb = (bf16_t*)h->arena.alloc((size_t)B * Tq * C * 2);
   bf16_t* kb = (bf16_t*)h->arena.alloc((size_t)B * Tk * C * 2);
   bf16_t* vb = (bf16_t*)h->arena.alloc((size_t)B * Tk * C * 2);
-  bf16_t* vt = (bf16_t*)h->arena.alloc((size_t)B * C * Tpad * 2);
   bf16_t* ob = (bf16_t*)h->arena.alloc((size_t)B * Tq * C * 2);
   launch_nchw_to_nhwc(h->st, q, qb, B * Tq, C, 1, C, 1.f, 0.f, 0);
   launch_nchw_to_nhwc(h->st, k, kb, B * Tk, C, 1, C, 1.f, 0.f, 0);
   launch_nchw_to_nhwc(h->st, v, vb, B * Tk, C, 1, C, 1.f, 0.f, 0);
-  launch_transpose_v(h->st, vb, C, (int64_t)Tk * C, vt, B, H, Tk, D, D, Tpad);
   AttnParams p;
-  p.q = qb; p.k = kb; p.vt = vt; p.o = ob; p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.D = D;
+  p.q = qb; p.k = kb; p.o = ob; p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.D = D;
   p.ldq = C; p.ldk = C; p.ldo = C; p.q_bs = (int64_t)Tq * C; p.k_bs = (int64_t)Tk * C; p.o_bs = (int64_t)Tq * C;
-  p.vt_dpad = D; p.vt_tpad = Tpad; p.scale = scale;
+  p.scale = scale;
+  if (use_transpose_kernel) {  // V^T [B][H][D][Tpad] layout (k_transpose_v), else token-major V (LDS transpose reads)
+    bf16_t* vt = (bf16_t*)h->arena.alloc((size_t)B * C * Tpad * 2);
+    launch_transpose_v(h->st, vb, C, (int64_t)Tk * C, vt, B, H, Tk, D, D, Tpad);
+    p.vt = vt; p.vt_dpad = D; p.vt_tpad = Tpad;
+  } else {
+    p.v = vb; p.ldv = C; p.v_bs = (int64_t)Tk * C;
+  }
   launch_attention(h->st, p);
   launch_nhwc_to_nchw(h->st, ob, 0, C, o, B * Tq, C, 1, 1.f, 0.f);
   CD_API_END
@@ -684,6 +688,26 @@ __global__ void k_probe_tr(float* out) {
   out[lane * 4 + 2] = bf2f((bf16_t)(v.y & 0xffff));
   out[lane * 4 + 3] = bf2f((bf16_t)(v.y >> 16));
 }
+// The address pattern k_attention uses for its PV A operand (token-major V tile [64 keys][96] in LDS): 16 lanes fetch a
+// 4-key x 16-d block, lane l must receive column d = dt*32 + (l & 31) of keys base + 4*(l >> 5) + 0..3.
+__global__ void k_probe_tr_attn(float* out) {
+  constexpr int VS = 96;
+  __shared__ __attribute__((aligned(16))) bf16_t lds[64 * VS];
+  const int lane = threadIdx.x & 63;
+  for (int i = lane; i < 64 * VS; i += 64) lds[i] = (bf16_t)((i / VS) * 64 + (i % VS < 64 ? i % VS : 0));  // raw key*64+d
+  __syncthreads();
+  typedef __attribute__((address_space(3))) bf16x4* lds4_t;
+  const int half = lane >> 5;
+  const int vtr_off = (4 * half + ((lane & 15) >> 2)) * VS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  int n = 0;
+  for (int sel = 0; sel < 2; ++sel) {  // (kh, s2, dt) = (0, 0, 0) and (1, 1, 1)
+    const bf16_t* vr = lds + vtr_off + (sel * 32 + 16 * sel) * VS + sel * 32;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)vr);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vr + 8 * VS));
+    for (int j = 0; j < 4; ++j) out[lane * 16 + n++] = (float)(unsigned short)lo[j];
+    for (int j = 0; j < 4; ++j) out[lane * 16 + n++] = (float)(unsigned short)hi[j];
+  }
+}
 }  // namespace
 
 namespace {
@@ -748,6 +772,9 @@ extern "C" int cd_op_probe(cd_handle h, int which, const void* in, void* out, si
   } else if (which == 1) {
     CD_CHECK(n >= 256 * sizeof(float), "probe 1 needs 256 floats");
     hipLaunchKernelGGL(k_probe_tr, dim3(1), dim3(64), 0, h->st, (float*)out);
+  } else if (which == 2) {
+    CD_CHECK(n >= 1024 * sizeof(float), "probe 2 needs 1024 floats");
+    hipLaunchKernelGGL(k_probe_tr_attn, dim3(1), dim3(64), 0, h->st, (float*)out);
   } else {
     CD_CHECK(false, "unknown probe %d", which);
   }

@@ -103,6 +103,24 @@ __device__ inline uint4 pack8(const float* f) {
   return r;
 }
 
+// Sum over the 64 lanes of a wave, result in every lane, without the LDS crossbar: quad_perm / row_half_mirror /
+// row_mirror DPP adds give every lane its row-of-16 total, row_bcast15 / row_bcast31 chain the four rows so that row 3
+// holds the wave total, v_readlane broadcasts it. 7 VALU operations; a __shfl_xor butterfly is 6 ds_bpermute round
+// trips. (v_permlane16/32_swap with both operands the same value is NOT usable from the builtin: the compiler folds
+// its two results into one register - measured as a wrong LayerNorm before this form.)
+#define CD_DPP_ADD(v, ctrl, row_mask) \
+  (v) += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), ctrl, row_mask, 0xf, false))
+__device__ inline float wave_allsum(float v) {
+  CD_DPP_ADD(v, 0xB1, 0xf);   // quad_perm [1 0 3 2]
+  CD_DPP_ADD(v, 0x4E, 0xf);   // quad_perm [2 3 0 1]
+  CD_DPP_ADD(v, 0x141, 0xf);  // row_half_mirror
+  CD_DPP_ADD(v, 0x140, 0xf);  // row_mirror: every lane = total of its 16-lane row
+  CD_DPP_ADD(v, 0x142, 0xa);  // row_bcast15 into rows 1 and 3 (the other rows add 0)
+  CD_DPP_ADD(v, 0x143, 0xc);  // row_bcast31 into rows 2 and 3: row 3 = total of the wave
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+#undef CD_DPP_ADD
+
 __device__ inline float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // <= 1 ulp exp: the fp32 path and the fp32 time-embedding MLP (the pixel 'ddim' chain amplifies every deviation from
 // the reference's fp32 arithmetic by 4-5 orders of magnitude)

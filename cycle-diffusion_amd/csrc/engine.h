@@ -156,10 +156,13 @@ Act upsample2_fwd(Ctx& c, const Act& x);
 // fp32 path: softmax(scale q k^T) v + obias with q | k in one token-major tensor and v in another
 Act attention_f32_fwd(Ctx& c, const Act& qk, const Act& v, int H, int D, float scale, const float* obias);
 
-// multi-head attention on token-major activations; vt is [B][H*D][Tpad]
-// q_log2: q already carries scale * log2(e) (folded into its projection weights); `scale` is then unused
-Act attention_fwd(Ctx& c, const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* vt, int B,
-                  int H, int Tq, int Tk, int Tpad, int D, float scale, int Himg, int Wimg, bool q_log2 = false);
+// multi-head attention on token-major activations: q [B][Tq][ldq], k [B][Tk][ldk], v [B][Tk][ldv] (head h at column
+// h*D of each). q_log2: q already carries scale * log2(e) (folded into its projection weights); `scale` is then unused
+Act attention_fwd(Ctx& c, const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv, int B,
+                  int H, int Tq, int Tk, int D, float scale, int Himg, int Wimg, bool q_log2 = false);
+// the same with V pre-transposed: vt [B][H*D][Tpad] (keys contiguous, zero padded to Tpad % 64 == 0)
+Act attention_vt_fwd(Ctx& c, const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* vt, int B,
+                     int H, int Tq, int Tk, int Tpad, int D, float scale, int Himg, int Wimg, bool q_log2 = false);
 
 // ------------------------------------------------------------------ networks
 class Net {

@@ -341,8 +341,22 @@ Act layernorm_fwd(Ctx& c, const LNW& w, const Act& x) {
   return y;
 }
 
-Act attention_fwd(Ctx& c, const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* vt, int B,
-                  int H, int Tq, int Tk, int Tpad, int D, float scale, int Himg, int Wimg, bool q_log2) {
+Act attention_fwd(Ctx& c, const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv, int B,
+                  int H, int Tq, int Tk, int D, float scale, int Himg, int Wimg, bool q_log2) {
+  CD_CHECK(!c.f32, "attention: 16-bit kernel called on the fp32 path");
+  Act o = alloc_act(c, B, Himg, Wimg, H * D);
+  AttnParams p;
+  p.q = q; p.k = k; p.v = v; p.o = o.p;
+  p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.D = D;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = o.ld;
+  p.q_bs = (int64_t)Tq * ldq; p.k_bs = (int64_t)Tk * ldk; p.v_bs = (int64_t)Tk * ldv; p.o_bs = (int64_t)Tq * o.ld;
+  p.scale = scale; p.q_log2 = q_log2 ? 1 : 0;
+  launch_attention(c.st, p);
+  return o;
+}
+
+Act attention_vt_fwd(Ctx& c, const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* vt, int B,
+                     int H, int Tq, int Tk, int Tpad, int D, float scale, int Himg, int Wimg, bool q_log2) {
   CD_CHECK(!c.f32, "attention: 16-bit kernel called on the fp32 path");
   Act o = alloc_act(c, B, Himg, Wimg, H * D);
   AttnParams p;

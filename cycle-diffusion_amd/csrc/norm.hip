@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(GroupNormParams p, int rows_pe
 // One wave per row, R rows per wave; C multiple of 8, C <= 64 * 8 * VPL. All 16-byte loads of the wave's R rows are
 // issued before any arithmetic: a single 640-byte row per wave (C = 320) keeps only ~5 MB in flight over the whole
 // chip, a third of what HBM latency x bandwidth needs; R = 4 puts the pass at the speed of the other streaming
-// kernels. Per-row arithmetic and reduction order are those of the one-row form (results are bit-identical).
+// kernels. Row sums by DPP / permlane swaps (wave_allsum), no LDS traffic.
 template <int VPL, int R>
 __global__ __launch_bounds__(256) void k_layernorm(const bf16_t* __restrict__ x, int ldx,
                                                    bf16_t* __restrict__ y, int ldy, int rows, int C,
@@ -275,8 +275,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const bf16_t* __restrict__ x,
         for (int e = 0; e < 8; ++e) s += f[j][e];
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s = wave_allsum(s);
     const float mean = s / (float)C;
     float q = 0.f;
 #pragma unroll
@@ -286,8 +285,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const bf16_t* __restrict__ x,
         for (int e = 0; e < 8; ++e) { const float d = f[j][e] - mean; q += d * d; }
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    q = wave_allsum(q);
     const float rstd = 1.0f / sqrtf(q / (float)C + eps);
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {

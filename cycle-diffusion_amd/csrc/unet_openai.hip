@@ -27,12 +27,15 @@ struct STW {  // SpatialTransformer with one BasicTransformerBlock
   GNW norm;
   ConvW *proj_in = nullptr, *proj_out = nullptr;
   LNW ln1, ln2, ln3;
-  ConvW *qk1 = nullptr, *v1 = nullptr, *o1 = nullptr;
+  // self-attention projections: fused [Wq * scale * log2(e); Wk; Wv] (V consumed token-major), or - d_head = 40,
+  // where the pre-transposed V^T layout is worth more to k_attention than the fusion - [Wq*; Wk] plus Wv kept as the
+  // A operand of a V^T = Wv . X^T GEMM
+  ConvW *qkv1 = nullptr, *qk1 = nullptr, *v1 = nullptr, *o1 = nullptr;
   ConvW *q2 = nullptr, *k2 = nullptr, *v2 = nullptr, *o2 = nullptr;
   ConvW *ff1 = nullptr, *ff2 = nullptr;
   // context cache (step invariant)
-  bf16_t* k2c = nullptr;   // [B*L][C]
-  bf16_t* vt2c = nullptr;  // [B][C][Tpad]
+  bf16_t* k2c = nullptr;  // [B*L][C]
+  bf16_t* v2c = nullptr;  // [B*L][C] (token-major: k_attention transposes V tiles with LDS transpose reads)
 };
 
 struct ABW {  // AttentionBlock (improved_ddpm/unet.py:268-315)
@@ -67,7 +70,7 @@ class UNetOpenAI : public UNet {
   Block mid_;
   GNW out_norm_;
   ConvW* out_conv_ = nullptr;
-  int ctx_B_ = 0, ctx_L_ = 0, ctx_Tpad_ = 0;
+  int ctx_B_ = 0, ctx_L_ = 0;
   std::vector<void*> ctx_allocs_;
 
   int add_res(const std::string& pfx, int cin, int cout, bool up, bool down);
@@ -130,14 +133,23 @@ int UNetOpenAI::add_st(const std::string& pfx, int C, int heads, int dh) {
   s.ln1 = make_ln(params, tb + ".norm1", C);
   s.ln2 = make_ln(params, tb + ".norm2", C);
   s.ln3 = make_ln(params, tb + ".norm3", C);
-  // self-attention: fused [Wq;Wk] GEMM, Wv kept as an A-operand matrix for the V^T GEMM.
   // to_q rows carry the softmax scale and log2(e) (attention.py:178: sim = q k^T * dim_head^-0.5), folded in
   // fp32 before the one rounding to 16 bits: q comes out of its GEMM in the log2 units k_attention consumes.
   const float qscale = 1.44269504088896340736f / sqrtf((float)dh);
-  s.qk1 = params.new_conv(2 * C, C, 1, 1, false);
-  params.conv_rows(tb + ".attn1.to_q.weight", {C, C}, s.qk1, 0, C, 0, C, 0, qscale);
-  params.conv_rows(tb + ".attn1.to_k.weight", {C, C}, s.qk1, C, C, 0, C, 0);
-  s.v1 = make_conv(params, tb + ".attn1.to_v", C, C, 1, false, false, 2);
+  // Measured on one box, B' = 32 (profiles/r2b_attention_v_layouts.txt): with token-major V the kernel's PV operand
+  // comes from LDS transpose reads - 7 % faster than the V^T layout at d = 80, 12 % slower at d = 40 (twice the LDS
+  // instructions for 41 useful rows); the fused q|k|v GEMM saves 17-26 us per block against [q|k] + V^T GEMMs.
+  if (dh == 40) {
+    s.qk1 = params.new_conv(2 * C, C, 1, 1, false);
+    params.conv_rows(tb + ".attn1.to_q.weight", {C, C}, s.qk1, 0, C, 0, C, 0, qscale);
+    params.conv_rows(tb + ".attn1.to_k.weight", {C, C}, s.qk1, C, C, 0, C, 0);
+    s.v1 = make_conv(params, tb + ".attn1.to_v", C, C, 1, false, false, 2);
+  } else {
+    s.qkv1 = params.new_conv(3 * C, C, 1, 1, false);
+    params.conv_rows(tb + ".attn1.to_q.weight", {C, C}, s.qkv1, 0, C, 0, C, 0, qscale);
+    params.conv_rows(tb + ".attn1.to_k.weight", {C, C}, s.qkv1, C, C, 0, C, 0);
+    params.conv_rows(tb + ".attn1.to_v.weight", {C, C}, s.qkv1, 2 * C, C, 0, C, 0);
+  }
   s.o1 = make_conv(params, tb + ".attn1.to_out.0", C, C, 1, true, false, 2);
   s.q2 = make_conv(params, tb + ".attn2.to_q", C, C, 1, false, false, 2, qscale);
   s.k2 = make_conv(params, tb + ".attn2.to_k", C, s.ctx, 1, false, false, 2);
@@ -346,23 +358,22 @@ static void vt_gemm(Ctx& c, const ConvW& wv, const bf16_t* x, int ldx, int B, in
 
 void UNetOpenAI::set_context(Ctx& c, const bf16_t* ctx, int B, int L) {
   if (st_.empty()) return;
-  const int Tpad = round_up(L, 64);
   if (B != ctx_B_ || L != ctx_L_) {
     for (void* p : ctx_allocs_) (void)hipFree(p);
     ctx_allocs_.clear();
     for (auto& s : st_) {
       HIP_CHECK(hipMalloc((void**)&s.k2c, (size_t)B * L * s.C * 2 + 256));
-      HIP_CHECK(hipMalloc((void**)&s.vt2c, (size_t)B * s.C * Tpad * 2 + 256));
-      HIP_CHECK(hipMemsetAsync(s.vt2c, 0, (size_t)B * s.C * Tpad * 2, c.st));
-      ctx_allocs_.push_back(s.k2c); ctx_allocs_.push_back(s.vt2c);
+      HIP_CHECK(hipMalloc((void**)&s.v2c, (size_t)B * L * s.C * 2 + 256));
+      ctx_allocs_.push_back(s.k2c); ctx_allocs_.push_back(s.v2c);
     }
-    ctx_B_ = B; ctx_L_ = L; ctx_Tpad_ = Tpad;
+    ctx_B_ = B; ctx_L_ = L;
   }
   Act cx; cx.p = (bf16_t*)ctx; cx.B = 1; cx.H = B * L; cx.W = 1; cx.C = st_[0].ctx; cx.ld = cx.C;
   for (auto& s : st_) {
     ConvOpts o; o.pad = 0; o.out = s.k2c; o.out_ld = s.C;
     conv_fwd(c, *s.k2, cx, nullptr, o);
-    vt_gemm(c, *s.v2, ctx, cx.ld, B, L, Tpad, s.vt2c);
+    o.out = s.v2c;
+    conv_fwd(c, *s.v2, cx, nullptr, o);
   }
 }
 
@@ -378,22 +389,29 @@ Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x) {
   {  // self-attention
     const size_t m2 = c.arena->mark();
     Act n1 = layernorm_fwd(c, s.ln1, h);
-    Act qk = conv_fwd(c, *s.qk1, n1, nullptr, p0);  // [B*T][2C]
-    const int Tpad = round_up(T, 64);
-    bf16_t* vt = (bf16_t*)c.arena->alloc((size_t)B * C * Tpad * 2);
-    if (Tpad != T) HIP_CHECK(hipMemsetAsync(vt, 0, (size_t)B * C * Tpad * 2, c.st));
-    vt_gemm(c, *s.v1, n1.p, n1.ld, B, T, Tpad, vt);
-    Act a = attention_fwd(c, qk.p, qk.ld, qk.p + C, qk.ld, vt, B, s.heads, T, T, Tpad, s.dh, scale, x.H, x.W,
-                          /*q_log2=*/true);
+    Act a;
+    if (s.qkv1) {
+      Act qkv = conv_fwd(c, *s.qkv1, n1, nullptr, p0);  // [B*T][3C] = q (log2 units) | k | v
+      a = attention_fwd(c, qkv.p, qkv.ld, qkv.p + C, qkv.ld, qkv.p + 2 * C, qkv.ld, B, s.heads, T, T, s.dh, scale,
+                        x.H, x.W, /*q_log2=*/true);
+    } else {
+      Act qk = conv_fwd(c, *s.qk1, n1, nullptr, p0);  // [B*T][2C]
+      const int Tpad = round_up(T, 64);
+      bf16_t* vt = (bf16_t*)c.arena->alloc((size_t)B * C * Tpad * 2);
+      if (Tpad != T) HIP_CHECK(hipMemsetAsync(vt, 0, (size_t)B * C * Tpad * 2, c.st));
+      vt_gemm(c, *s.v1, n1.p, n1.ld, B, T, Tpad, vt);
+      a = attention_vt_fwd(c, qk.p, qk.ld, qk.p + C, qk.ld, vt, B, s.heads, T, T, Tpad, s.dh, scale, x.H, x.W,
+                           /*q_log2=*/true);
+    }
     ConvOpts o; o.pad = 0; o.resid = &h; o.out = h.p; o.out_ld = h.ld;  // in-place residual update:
     conv_fwd(c, *s.o1, a, nullptr, o);  // each element is read then written by the same lane
     c.arena->release(m2);
   }
-  {  // cross-attention over the cached context K / V^T
+  {  // cross-attention over the cached context K / V
     const size_t m2 = c.arena->mark();
     Act n2 = layernorm_fwd(c, s.ln2, h);
     Act q = conv_fwd(c, *s.q2, n2, nullptr, p0);
-    Act a = attention_fwd(c, q.p, q.ld, s.k2c, C, s.vt2c, B, s.heads, T, ctx_L_, ctx_Tpad_, s.dh, scale, x.H, x.W,
+    Act a = attention_fwd(c, q.p, q.ld, s.k2c, C, s.v2c, C, B, s.heads, T, ctx_L_, s.dh, scale, x.H, x.W,
                           /*q_log2=*/true);
     ConvOpts o; o.pad = 0; o.resid = &h; o.out = h.p; o.out_ld = h.ld;  // in-place residual update
     conv_fwd(c, *s.o2, a, nullptr, o);

@@ -176,7 +176,8 @@ int cd_op_groupnorm(cd_handle h, const float* x, int B, int C, int H, int W, int
                     const float* gamma, const float* beta, const float* film, int silu, float* y);
 int cd_op_layernorm(cd_handle h, const float* x, int rows, int C, const float* gamma, const float* beta,
                     float eps, float* y);
-/* q [B,Tq,H*D], k,v [B,Tk,H*D] fp32 -> o [B,Tq,H*D] */
+/* q [B,Tq,H*D], k,v [B,Tk,H*D] fp32 -> o [B,Tq,H*D]; use_transpose_kernel: 0 = V consumed token-major (the U-Net
+   path: fused q|k|v projection, LDS transpose reads), 1 = V pre-transposed to [B,H,D,Tk_pad] first */
 int cd_op_attention(cd_handle h, const float* q, const float* k, const float* v, int B, int H, int Tq,
                     int Tk, int D, float scale, int use_transpose_kernel, float* o);
 int cd_op_softmax_rows(cd_handle h, const float* s, int64_t rows, int cols, float* p);

@@ -1,6 +1,10 @@
 """Time the fused attention kernel on one self-attention shape of the SD U-Net (default: 64x64 level, d = 40).
 
   python scripts/bench_attn.py [B] [T] [heads] [d] [iters]
+
+Runs both V layouts of k_attention (token-major V with LDS transpose reads, and V^T pre-transposed by k_transpose_v);
+kernel times: rocprofv3 --kernel-trace + scripts/kernel_breakdown.py (the wall time below includes the fp32 <-> 16-bit
+layout conversions of the test entry point).
 """
 import sys
 import time
@@ -27,15 +31,17 @@ o = torch.empty_like(q)
 scale = D ** -0.5
 
 
-def run():
-    check(eng.lib.cd_op_attention(eng.h, ptr(q), ptr(k), ptr(v), B, H, T, T, D, C.c_float(scale), 1, ptr(o)))
+def run(vt):
+    check(eng.lib.cd_op_attention(eng.h, ptr(q), ptr(k), ptr(v), B, H, T, T, D, C.c_float(scale), vt, ptr(o)))
 
 
-run()
-torch.cuda.synchronize()
-t0 = time.time()
-for _ in range(iters):
-    run()
-torch.cuda.synchronize()
-ms = (time.time() - t0) / iters * 1e3
-print("B=%d T=%d H=%d d=%d: %.3f ms per call incl. layout conversions (kernel time: see rocprofv3)" % (B, T, H, D, ms))
+for vt in (0, 1):
+    run(vt)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(iters):
+        run(vt)
+    torch.cuda.synchronize()
+    ms = (time.time() - t0) / iters * 1e3
+    print("B=%d T=%d H=%d d=%d %s: %.3f ms per call incl. layout conversions (kernel time: see rocprofv3)"
+          % (B, T, H, D, "V^T" if vt else "V token-major", ms))

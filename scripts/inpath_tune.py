@@ -20,6 +20,9 @@ BASE = os.path.join(ROOT, "cycle-diffusion_amd", "tune_gfx950.txt")
 BK32 = 1 << 16
 # tile ids: conv_gemm.hip kCfgs. Deeper rings / smaller K steps / wider tiles than the warm tuner tends to pick.
 CANDIDATES = [22 | BK32, 5 | BK32, 10 | BK32, 16 | BK32, 6 | BK32, 20, 23, 13 | BK32, 1 | BK32]
+if os.environ.get("INPATH_CANDIDATES"):  # e.g. "65560,65561,26" = 24 | BK32, 25 | BK32, 26
+    CANDIDATES = [int(x) for x in os.environ["INPATH_CANDIDATES"].split(",")]
+BATCHES = [int(x) for x in os.environ.get("INPATH_BATCHES", "16,32").split(",")]
 LINE = re.compile(r"\s+M(\d+) N(\d+) K(\d+) k(\d) s(\d)( up)?( cat)? z(\d+) act(\d) \| (.*?)\s+n=\s*(\d+)\s+([\d.]+) ms\s+([\d.]+) us/launch")
 
 
@@ -71,12 +74,12 @@ def main():
             for r in rows:
                 fh.write(" ".join(str(x) for x in r) + "\n")
         merged = {}
-        for B in (16, 32):
+        for B in BATCHES:
             for k, ms in run_forward(path, B).items():
                 merged[k] = merged.get(k, 0.0) + ms
         results[cand] = merged
         tot = sum(ms for k, ms in merged.items() if k in targets)
-        print("candidate %s: short-K shapes %.3f ms per (B'=16 + B'=32) forward pair" % (cand, tot), flush=True)
+        print("candidate %s: short-K shapes %.3f ms per forward set B' = %s" % (cand, tot, BATCHES), flush=True)
     best = {}
     for t in targets:
         opts = [(results[c].get(t, 1e30), c) for c in results]

@@ -95,13 +95,13 @@ def layernorm(eng, x, gamma, beta, eps=1e-5):
     return y.cpu()
 
 
-def attention(eng, q, k, v, heads, scale):
+def attention(eng, q, k, v, heads, scale, v_transposed=False):
     B, Tq, Cc = q.shape
     Tk = k.shape[1]
     o = torch.empty_like(q, device="cuda")
     qs, ks, vs = dev(q), dev(k), dev(v)
     check(eng.lib.cd_op_attention(eng.h, ptr(qs), ptr(ks), ptr(vs), B, heads, Tq, Tk, Cc // heads,
-                                  C.c_float(scale), 1, ptr(o)))
+                                  C.c_float(scale), 1 if v_transposed else 0, ptr(o)))
     torch.cuda.synchronize()
     return o.cpu()
 

@@ -51,6 +51,22 @@ def test_probe_tr_read(engine, report):
     assert np.isfinite(out).all()
 
 
+def test_probe_tr_read_attention_pattern(engine, report):
+    # the LDS transpose read as k_attention addresses it (token-major V tile, row stride 96): lane l must receive, for
+    # its d column (dt*32 + l%32), the four keys base + 4*(l//32) + 0..3 and the four 8 keys further on
+    out = _ops.probe(engine, 2, 1024).reshape(64, 2, 2, 4)  # lane, sel (kh=s2=dt=sel), piece, j
+    lane = np.arange(64)[:, None, None, None]
+    sel = np.arange(2)[None, :, None, None]
+    piece = np.arange(2)[None, None, :, None]
+    j = np.arange(4)[None, None, None, :]
+    key = sel * 32 + 16 * sel + 8 * piece + 4 * (lane >> 5) + j
+    d = sel * 32 + (lane & 31)
+    want = key * 64 + d
+    report.add("probe_tr_attn", ok=bool((out == want).all()), lane0=out[0].reshape(-1).tolist(),
+               lane37=out[37].reshape(-1).tolist())
+    assert (out == want).all(), (out[0], want[0], out[37], want[37])
+
+
 CONV_CASES = [
     # name, B, C0, C1, H, W, N, k, stride, pad, asym, up, bias, rowvec, resid, act, tile
     ("3x3_64_64_16", 2, 64, 0, 16, 16, 64, 3, 1, 1, False, False, True, False, False, 0, 0),
@@ -193,8 +209,10 @@ ATTN_CASES = [("d40_self", 2, 8, 256, 256, 40), ("d80_self", 1, 8, 256, 256, 80)
               ("d32_1head", 1, 1, 64, 64, 32), ("d128_1head", 1, 1, 320, 320, 128), ("d40_long", 1, 2, 1024, 1024, 40)]
 
 
+@pytest.mark.parametrize("vt", [False, True], ids=["v_token_major", "v_transposed"])
 @pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
-def test_attention(engine, report, case):
+def test_attention(engine, report, case, vt):
+    # both V layouts of k_attention: token-major (fused q|k|v output, LDS transpose reads) and pre-transposed V^T
     name, B, H, Tq, Tk, D = case
     g = torch.Generator().manual_seed(17)
     C = H * D
@@ -207,12 +225,13 @@ def test_attention(engine, report, case):
     vh = v.view(B, Tk, H, D).transpose(1, 2)
     att = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1)
     ref = (att @ vh).transpose(1, 2).reshape(B, Tq, C)
-    got = _ops.attention(engine, q, k, v, H, scale)
-    _check(report, "attention/" + name, got, ref, rel=2e-2, mean=1e-2)
+    got = _ops.attention(engine, q, k, v, H, scale, v_transposed=vt)
+    _check(report, "attention/%s/%s" % (name, "vt" if vt else "v"), got, ref, rel=2e-2, mean=1e-2)
 
 
+@pytest.mark.parametrize("vt", [False, True], ids=["v_token_major", "v_transposed"])
 @pytest.mark.parametrize("case", ["wide", "spike", "cross_spike"])
-def test_attention_deferred_max(engine, report, case):
+def test_attention_deferred_max(engine, report, case, vt):
     """The attention kernel keeps a stale reference maximum and only moves it when a row's scores outgrow it by 2^8
     (attn.hip). The move is a rare, data-dependent branch: bounded random scores never take it after the first
     tile, so these inputs force it - a wide score distribution (log2-unit std ~6: the maximum of almost every row
@@ -238,8 +257,8 @@ def test_attention_deferred_max(engine, report, case):
     vh = v.view(B, Tk, H, D).transpose(1, 2).double()
     att = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1)
     ref = (att @ vh).transpose(1, 2).reshape(B, Tq, C).float()
-    got = _ops.attention(engine, q, k, v, H, scale)
-    _check(report, "attention_deferred_max/" + case, got, ref, rel=2e-2, mean=1e-2)
+    got = _ops.attention(engine, q, k, v, H, scale, v_transposed=vt)
+    _check(report, "attention_deferred_max/%s/%s" % (case, "vt" if vt else "v"), got, ref, rel=2e-2, mean=1e-2)
 
 
 def test_softmax_rows(engine, report):
