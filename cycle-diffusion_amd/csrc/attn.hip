@@ -44,8 +44,8 @@ constexpr int KT = 64;  // keys per tile
 // probabilities the numerator uses) instead of 32 VALU adds per tile.
 // NBUF = 2: the next tile's K / V^T are fetched into registers before the current tile's math and
 // written to the other LDS buffer after it - one barrier per tile.
-template <int DQK, int DV, int DH, int NBUF, bool VTOK>
-__global__ __launch_bounds__(256, DV <= 96 ? 2 : 1) void k_attention(AttnParams p) {
+template <int DQK, int DV, int DH, int NBUF, bool VTOK, int KG>
+__global__ __launch_bounds__(256, DV <= 96 ? (KG == 32 ? 4 : 2) : 1) void k_attention(AttnParams p) {
   constexpr int KLD = DQK + 8;  // elements per K row in LDS (16 B pad)
   constexpr int VLD = KT + 8;   // elements per V^T row in LDS
   constexpr int NKS = DQK / 16;
@@ -95,54 +95,54 @@ __global__ __launch_bounds__(256, DV <= 96 ? 2 : 1) void k_attention(AttnParams 
     }
   }
 
-  // ---- staging plan (fixed per thread): K tile [64][DQK] zero padded, V^T tile [DV][64]
-  int k_goff[NKR], k_loff[NKR], k_row[NKR];
-  int v_loff[NVR], v_row[NVR];
+  // ---- staging plan (fixed per thread): K tile [64][DQK] zero padded, V^T tile [DV][64] / V tile [64][VS].
+  // Global reads are buffer loads: a 32-bit per-thread byte offset (kNoLoad = out of range for inactive slots), the
+  // tile's position as the scalar offset, and a descriptor whose size ends at the last valid row - rows beyond Tk
+  // (beyond vt_dpad for V^T) arrive as zeros from the bounds check, without branches or 64-bit address arithmetic.
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  constexpr unsigned kNoLoad = 0x80000000u;
+  const unsigned k_bytes = p.Tk > 0 ? (unsigned)(((int64_t)(p.Tk - 1) * p.ldk + D) * 2) : 0u;
+  const unsigned v_bytes = VTOK ? (p.Tk > 0 ? (unsigned)(((int64_t)(p.Tk - 1) * p.ldv + D) * 2) : 0u)
+                                : (unsigned)((int64_t)p.vt_dpad * p.vt_tpad * 2);
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vtb, 0, v_bytes, 0x00020000);
+  unsigned k_voff[NKR], v_voff[NVR];
+  int k_loff[NKR], v_loff[NVR];
   bool v_ones[NVR];
-  int64_t v_goff[NVR];
 #pragma unroll
   for (int i = 0; i < NKR; ++i) {
     const int id = tid + i * 256;
     const int row = id / CPR, ch = id % CPR;
-    const bool ok = id < KT * CPR && ch * 8 < D;
-    k_row[i] = ok ? row : (1 << 30);  // never < Tk
-    k_goff[i] = row * p.ldk + ch * 8;
+    const bool ok = id < KT * CPR && ch * 8 < D;  // columns D .. DQK-1 of the tile are zero padding
+    k_voff[i] = ok ? (unsigned)((row * p.ldk + ch * 8) * 2) : kNoLoad;
     k_loff[i] = id < KT * CPR ? row * KLD + ch * 8 : -1;
   }
 #pragma unroll
   for (int i = 0; i < NVR; ++i) {
     const int id = tid + i * 256;
-    if (VTOK) {  // [key][d] like K: chunk ch of key row `row`; v_row = key row (or out of range), chunk CPRV-1 = ones
+    if (VTOK) {  // [key][d] like K: chunk ch of key row `row`; chunk CPRV-1 = the ones column when ONES
       const int row = id / CPRV, ch = id % CPRV;
       const bool data = id < KT * CPRV && ch * 8 < D;
-      v_row[i] = data ? row : (1 << 30);
-      v_goff[i] = (int64_t)row * p.ldv + ch * 8;
+      v_voff[i] = data ? (unsigned)((row * p.ldv + ch * 8) * 2) : kNoLoad;
       v_loff[i] = id < KT * CPRV ? row * VS + ch * 8 : -1;
       v_ones[i] = ONES && ch * 8 == DH;
     } else {
       const int row = id >> 3, ch = id & 7;
-      v_row[i] = row;
-      v_goff[i] = (int64_t)row * p.vt_tpad + ch * 8;
+      v_voff[i] = (unsigned)((row * p.vt_tpad + ch * 8) * 2);  // rows >= vt_dpad fall outside the descriptor
       v_loff[i] = row * VLD + (ch >> 1) * 16 + (ch & 1) * 4;
-      v_ones[i] = false;
+      v_ones[i] = ONES && row == DH;
     }
   }
   uint4 kreg[NKR], vreg[NVR];
   auto fetch = [&](int key0) {
+    const int k_soff = key0 * p.ldk * 2;
+    const int v_soff = VTOK ? key0 * p.ldv * 2 : key0 * 2;
 #pragma unroll
-    for (int i = 0; i < NKR; ++i) {
-      kreg[i] = make_uint4(0, 0, 0, 0);
-      if (key0 + k_row[i] < p.Tk && k_row[i] < KT) kreg[i] = *(const uint4*)(kb + (int64_t)key0 * p.ldk + k_goff[i]);
-    }
+    for (int i = 0; i < NKR; ++i)
+      kreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_k, k_voff[i], k_soff, 0));
 #pragma unroll
-    for (int i = 0; i < NVR; ++i) {
-      vreg[i] = make_uint4(0, 0, 0, 0);
-      if (VTOK) {  // keys beyond Tk are zero rows (their probabilities are zero, 0 * garbage must not be NaN)
-        if (key0 + v_row[i] < p.Tk && v_row[i] < KT) vreg[i] = *(const uint4*)(vtb + (int64_t)key0 * p.ldv + v_goff[i]);
-      } else {
-        if (v_row[i] < p.vt_dpad) vreg[i] = *(const uint4*)(vtb + v_goff[i] + key0);
-      }
-    }
+    for (int i = 0; i < NVR; ++i)
+      vreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, v_voff[i], v_soff, 0));
   };
   // VTOK = false: V^T rows are stored with the four 4-key pieces of every 16-key group in the order [0 2 1 3]: the
   // two pieces a lane feeds to one PV MFMA (keys 4*half.. and 8+4*half.., the accumulator layout of S^T) are then one
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, DV <= 96 ? 2 : 1) void k_attention(AttnParams 
         if (v_ones[i]) v = make_uint4(kOnePair & 0xffffu, 0, 0, 0);  // column DH = 1, the rest of the chunk 0
         if (v_loff[i] >= 0) *(uint4*)(&Vs[buf][v_loff[i]]) = v;
       } else {
-        if (ONES && v_row[i] == DH) v = make_uint4(kOnePair, kOnePair, kOnePair, kOnePair);
+        if (v_ones[i]) v = make_uint4(kOnePair, kOnePair, kOnePair, kOnePair);
         *(uint2*)(&Vs[buf][v_loff[i]]) = make_uint2(v.x, v.y);
         *(uint2*)(&Vs[buf][v_loff[i] + 8]) = make_uint2(v.z, v.w);
       }
@@ -192,97 +192,112 @@ __global__ __launch_bounds__(256, DV <= 96 ? 2 : 1) void k_attention(AttnParams 
     const bf16_t* Kt = Ks[buf];
     const bf16_t* Vt = Vs[buf];
 
-    // ---- S^T - m = K Q^T - m for the two 32-key halves of the tile
-    f32x16 s[2];
-    {
-      bf16x8 kf[2][NKS];  // all K fragments first: the LDS latency is paid once, not per MFMA
+    // The tile is consumed in groups of KG keys (KG = 64: both 32-key halves at once; KG = 32: one half at a time -
+    // half the score / probability registers live, one more wave per SIMD where that crosses an occupancy step).
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
+    for (int g = 0; g < KT / KG; ++g) {
+      constexpr int HPG = KG / 32;  // 32-key halves per group
+      // ---- S^T - m = K Q^T - m
+      f32x16 s[HPG];
+      {
+        bf16x8 kf[HPG][NKS];  // all K fragments first: the LDS latency is paid once, not per MFMA
+#pragma unroll
+        for (int kh = 0; kh < HPG; ++kh)
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks)
+            kf[kh][ks] = *(const bf16x8*)(Kt + ((g * HPG + kh) * 32 + qi) * KLD + ks * 16 + 8 * half);
+        if (KG == 64) __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs (else re-serialised)
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
-          kf[kh][ks] = *(const bf16x8*)(Kt + (kh * 32 + qi) * KLD + ks * 16 + 8 * half);
-      __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs (the scheduler re-serialises them)
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)  // the two 32-key halves alternate: no back-to-back dependent MFMAs
-          s[kh] = CD_MFMA_32x32x16(kf[kh][ks], qf[ks], ks == 0 ? negm : s[kh]);
-    }
-    // ---- keys beyond Tk (last tile only) / causal mask
-    if (key0 + KT > p.Tk || p.causal) {
-      const int kmax = p.causal ? min(p.Tk - 1, q0 + qi) : p.Tk - 1;  // last visible key of this lane's query
-#pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = key0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          s[kh][r] = key <= kmax ? s[kh][r] : -INFINITY;
-        }
-    }
-    // tile maximum relative to m. v_max3 directly: fmaxf() would first canonicalise every MFMA result
-    float mx;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(s[0][0]), "v"(s[1][0]), "v"(s[0][1]));
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[1][1]), "v"(s[0][2]));
-#pragma unroll
-    for (int r = 3; r < 16; ++r)
-      asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[1][r - 1]), "v"(s[0][r]));
-    asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(s[1][15]));
-    // ---- move m (rare, wave-uniform): always on the first tile, later only if a row grew past 2^kDefer.
-    // Textbook order: the decision precedes the exponentiation of the tile it covers, and everything
-    // accumulated against the old m (o, the row sums inside o or l_part) is rescaled exactly once.
-    if (t == 0 || __any(mx > kDefer)) {
-      const float mxq = fmaxf(mx, __shfl_xor(mx, 32));  // both half-lanes of a query agree
-      float delta = t == 0 ? mxq : fmaxf(mxq, 0.f);
-      delta = delta == -INFINITY ? 0.f : delta;
-      const float alpha = __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kh][r] -= delta;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) negm[r] -= delta;
-#pragma unroll
-      for (int i = 0; i < NDT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-      l_part *= alpha;
-    }
-    uint32_t pw[2][8];
-    float ps = 0.f;
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const float e0 = __builtin_amdgcn_exp2f(s[kh][r]);
-        const float e1 = __builtin_amdgcn_exp2f(s[kh][r + 1]);
-        if (!ONES) ps += e0 + e1;
-        pw[kh][r >> 1] = pack2_prob(e0, e1);
+          for (int kh = 0; kh < HPG; ++kh)  // the 32-key halves alternate: no back-to-back dependent MFMAs
+            s[kh] = CD_MFMA_32x32x16(kf[kh][ks], qf[ks], ks == 0 ? negm : s[kh]);
       }
-    if (!ONES) l_part += ps;
-
-    // ---- O^T += V^T P^T
+      // ---- keys beyond Tk (last tile only) / causal mask
+      if (key0 + KT > p.Tk || p.causal) {
+        const int kmax = p.causal ? min(p.Tk - 1, q0 + qi) : p.Tk - 1;  // last visible key of this lane's query
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
+        for (int kh = 0; kh < HPG; ++kh)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const uint4 praw = make_uint4(pw[kh][4 * s2], pw[kh][4 * s2 + 1], pw[kh][4 * s2 + 2], pw[kh][4 * s2 + 3]);
-        const bf16x8 pf = __builtin_bit_cast(bf16x8, praw);
-        const int kbase = kh * 32 + 16 * s2 + 8 * half;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-          bf16x8 vf;
-          if (VTOK) {
-            typedef __attribute__((address_space(3))) bf16x4* lds4_t;
-            const bf16_t* vr = Vt + vtr_off + (kh * 32 + 16 * s2) * VS + dt * 32;
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)vr);
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vr + 8 * VS));
-            vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          } else {
-            vf = *(const bf16x8*)(Vt + (dt * 32 + qi) * VLD + kbase);
+          for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (g * HPG + kh) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            s[kh][r] = key <= kmax ? s[kh][r] : -INFINITY;
           }
-          o[dt] = CD_MFMA_32x32x16(vf, pf, o[dt]);
-        }
       }
+      // group maximum relative to m. v_max3 directly: fmaxf() would first canonicalise every MFMA result
+      float mx;
+      if (HPG == 2) {
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(s[0][0]), "v"(s[HPG - 1][0]), "v"(s[0][1]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[HPG - 1][1]), "v"(s[0][2]));
+#pragma unroll
+        for (int r = 3; r < 16; ++r)
+          asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[HPG - 1][r - 1]), "v"(s[0][r]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(s[HPG - 1][15]));
+      } else {
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]));
+#pragma unroll
+        for (int r = 3; r < 15; r += 2)
+          asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[0][r]), "v"(s[0][r + 1]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(s[0][15]));
+      }
+      // ---- move m (rare, wave-uniform): always on the first group, later only if a row grew past 2^kDefer.
+      // Textbook order: the decision precedes the exponentiation of the keys it covers, and everything
+      // accumulated against the old m (o, the row sums inside o or l_part) is rescaled exactly once.
+      const bool first = t == 0 && g == 0;
+      if (first || __any(mx > kDefer)) {
+        const float mxq = fmaxf(mx, __shfl_xor(mx, 32));  // both half-lanes of a query agree
+        float delta = first ? mxq : fmaxf(mxq, 0.f);
+        delta = delta == -INFINITY ? 0.f : delta;
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int kh = 0; kh < HPG; ++kh)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[kh][r] -= delta;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] -= delta;
+#pragma unroll
+        for (int i = 0; i < NDT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        l_part *= alpha;
+      }
+      uint32_t pw[HPG][8];
+      float ps = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < HPG; ++kh)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float e0 = __builtin_amdgcn_exp2f(s[kh][r]);
+          const float e1 = __builtin_amdgcn_exp2f(s[kh][r + 1]);
+          if (!ONES) ps += e0 + e1;
+          pw[kh][r >> 1] = pack2_prob(e0, e1);
+        }
+      if (!ONES) l_part += ps;
+
+      // ---- O^T += V^T P^T
+#pragma unroll
+      for (int kh = 0; kh < HPG; ++kh)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const uint4 praw = make_uint4(pw[kh][4 * s2], pw[kh][4 * s2 + 1], pw[kh][4 * s2 + 2], pw[kh][4 * s2 + 3]);
+          const bf16x8 pf = __builtin_bit_cast(bf16x8, praw);
+          const int k16 = (g * HPG + kh) * 32 + 16 * s2;  // first key of this 16-key MFMA slice
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) {
+            bf16x8 vf;
+            if (VTOK) {
+              typedef __attribute__((address_space(3))) bf16x4* lds4_t;
+              const bf16_t* vr = Vt + vtr_off + k16 * VS + dt * 32;
+              const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)vr);
+              const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(vr + 8 * VS));
+              vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            } else {
+              vf = *(const bf16x8*)(Vt + (dt * 32 + qi) * VLD + k16 + 8 * half);
+            }
+            o[dt] = CD_MFMA_32x32x16(vf, pf, o[dt]);
+          }
+        }
+    }
 
     if (NBUF == 1) __syncthreads();
     if (more) commit(NBUF == 2 ? (buf ^ 1) : 0);
@@ -359,12 +374,15 @@ void launch_attention(hipStream_t st, const AttnParams& p) {
   else CD_CHECK((p.ldv % 8) == 0 && ((uintptr_t)p.v & 15) == 0, "attention: V row stride / alignment");
   CD_CHECK((p.ldq % 8) == 0 && (p.ldk % 8) == 0 && (p.ldo % 4) == 0, "attention: leading dims");
   dim3 grid(ceil_div(p.Tq, 128), p.H, p.B);
-#define CD_ATTN(DQK, DV, DH, NBUF)                                                                       \
-  do {                                                                                                   \
-    if (p.v) hipLaunchKernelGGL((k_attention<DQK, DV, DH, NBUF, true>), grid, dim3(256), 0, st, p);       \
-    else hipLaunchKernelGGL((k_attention<DQK, DV, DH, NBUF, false>), grid, dim3(256), 0, st, p);          \
+#define CD_ATTN_KG(DQK, DV, DH, NBUF, KG)                                                                    \
+  do {                                                                                                      \
+    if (p.v) hipLaunchKernelGGL((k_attention<DQK, DV, DH, NBUF, true, KG>), grid, dim3(256), 0, st, p);      \
+    else hipLaunchKernelGGL((k_attention<DQK, DV, DH, NBUF, false, KG>), grid, dim3(256), 0, st, p);         \
   } while (0)
-  if (p.D == 40) CD_ATTN(48, 64, 40, 2);       // SD / LDM 320-channel level
+#define CD_ATTN(DQK, DV, DH, NBUF) CD_ATTN_KG(DQK, DV, DH, NBUF, 64)
+  static const bool half_groups = [] { const char* e = getenv("CD_ATTN_KG32"); return e && e[0] == '1'; }();
+  if (p.D == 40 && half_groups) CD_ATTN_KG(48, 64, 40, 2, 32);  // experiment: 32-key softmax groups, 4 waves / SIMD
+  else if (p.D == 40) CD_ATTN(48, 64, 40, 2);  // SD / LDM 320-channel level
   else if (p.D == 80) CD_ATTN(80, 96, 80, 2);  // 640-channel level
   else if (p.D <= 32) CD_ATTN(32, 32, 0, 2);
   else if (p.D <= 48) CD_ATTN(48, 64, 0, 2);
@@ -374,6 +392,7 @@ void launch_attention(hipStream_t st, const AttnParams& p) {
   else if (p.D <= 128) CD_ATTN(128, 128, 0, 1);
   else CD_ATTN(160, 160, 0, 1);
 #undef CD_ATTN
+#undef CD_ATTN_KG
 }
 
 void launch_transpose_v(hipStream_t st, const bf16_t* v, int ldv, int64_t v_bs, bf16_t* vt, int B,

@@ -204,6 +204,22 @@ def test_layernorm(engine, report, C, rows):
     _check(report, "layernorm/c%d" % C, got, ref, rel=1.5e-2, mean=4e-3)
 
 
+def test_16bit_stores_saturate(engine, report):
+    """16-bit activation stores saturate at the format's largest finite value instead of
+    overflowing to inf (fp16: +-65504). A LayerNorm with a huge gain drives every output past the range."""
+    g = torch.Generator().manual_seed(29)
+    x = r16(torch.randn(33, 320, generator=g))
+    got = _ops.layernorm(engine, x, torch.full((320,), 3.0e5), torch.zeros(320))
+    ref = F.layer_norm(x, (320,), torch.full((320,), 3.0e5), torch.zeros(320), 1e-5)
+    fmt_max = 65504.0 if engine.lib.cd_act_format() == 1 else 3.3895313892515355e38
+    report.add("saturation/layernorm", finite=bool(torch.isfinite(got).all()), max=float(got.abs().max()))
+    assert torch.isfinite(got).all()
+    assert float(got.abs().max()) <= fmt_max
+    if engine.lib.cd_act_format() == 1:
+        big = ref.abs() > 7.0e4
+        assert big.any() and torch.equal(got[big], torch.sign(ref[big]) * fmt_max)
+
+
 ATTN_CASES = [("d40_self", 2, 8, 256, 256, 40), ("d80_self", 1, 8, 256, 256, 80), ("d160_self", 1, 8, 64, 64, 160),
               ("d40_cross77", 2, 8, 256, 77, 40), ("d160_cross77", 1, 8, 64, 77, 160), ("d64_iddpm", 1, 4, 256, 256, 64),
               ("d32_1head", 1, 1, 64, 64, 32), ("d128_1head", 1, 1, 320, 320, 128), ("d40_long", 1, 2, 1024, 1024, 40)]
