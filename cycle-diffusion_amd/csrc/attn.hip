@@ -45,7 +45,7 @@ constexpr int KT = 64;  // keys per tile
 // NBUF = 2: the next tile's K / V^T are fetched into registers before the current tile's math and
 // written to the other LDS buffer after it - one barrier per tile.
 template <int DQK, int DV, int DH, int NBUF, bool VTOK, int KG>
-__global__ __launch_bounds__(256, DV <= 96 ? (KG == 32 ? 4 : 2) : 1) void k_attention(AttnParams p) {
+__global__ __launch_bounds__(256, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3) : 2) : 1) void k_attention(AttnParams p) {
   constexpr int KLD = DQK + 8;  // elements per K row in LDS (16 B pad)
   constexpr int VLD = KT + 8;   // elements per V^T row in LDS
   constexpr int NKS = DQK / 16;
@@ -224,22 +224,21 @@ __global__ __launch_bounds__(256, DV <= 96 ? (KG == 32 ? 4 : 2) : 1) void k_atte
             s[kh][r] = key <= kmax ? s[kh][r] : -INFINITY;
           }
       }
-      // group maximum relative to m. v_max3 directly: fmaxf() would first canonicalise every MFMA result
-      float mx;
+      // group maximum relative to m. v_max3 through asm: fmaxf() would first canonicalise every MFMA result (one extra
+      // VALU op each). hipcc pads no hazards for an asm statement, and an MFMA's D needs 12 wait states before any
+      // reader: the chain therefore STARTS with a compiler-visible VALU read (v_med3 with +inf = max) of the accumulator
+      // the last MFMA wrote - hipcc pads that one, every asm op depends on it, and all earlier MFMAs have retired by then.
+      // (Rounds 1-2a started with the asm op: a latent hazard, visible as run-to-run differences once the 32-key groups
+      // put the reader right behind a dependent MFMA chain.)
+      float mx = __builtin_amdgcn_fmed3f(s[HPG - 1][14], s[HPG - 1][15], INFINITY);
       if (HPG == 2) {
-        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(s[0][0]), "v"(s[HPG - 1][0]), "v"(s[0][1]));
-        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[HPG - 1][1]), "v"(s[0][2]));
 #pragma unroll
-        for (int r = 3; r < 16; ++r)
-          asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[HPG - 1][r - 1]), "v"(s[0][r]));
-        asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(s[HPG - 1][15]));
-      } else {
-        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]));
-#pragma unroll
-        for (int r = 3; r < 15; r += 2)
-          asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[0][r]), "v"(s[0][r + 1]));
-        asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(s[0][15]));
+        for (int r = 0; r < 14; r += 2)
+          asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[1][r]), "v"(s[1][r + 1]));
       }
+#pragma unroll
+      for (int r = 0; r < (HPG == 2 ? 16 : 14); r += 2)
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[0][r]), "v"(s[0][r + 1]));
       // ---- move m (rare, wave-uniform): always on the first group, later only if a row grew past 2^kDefer.
       // Textbook order: the decision precedes the exponentiation of the keys it covers, and everything
       // accumulated against the old m (o, the row sums inside o or l_part) is rescaled exactly once.
@@ -380,10 +379,13 @@ void launch_attention(hipStream_t st, const AttnParams& p) {
     else hipLaunchKernelGGL((k_attention<DQK, DV, DH, NBUF, false, KG>), grid, dim3(256), 0, st, p);         \
   } while (0)
 #define CD_ATTN(DQK, DV, DH, NBUF) CD_ATTN_KG(DQK, DV, DH, NBUF, 64)
-  static const bool half_groups = [] { const char* e = getenv("CD_ATTN_KG32"); return e && e[0] == '1'; }();
-  if (p.D == 40 && half_groups) CD_ATTN_KG(48, 64, 40, 2, 32);  // experiment: 32-key softmax groups, 4 waves / SIMD
-  else if (p.D == 40) CD_ATTN(48, 64, 40, 2);  // SD / LDM 320-channel level
-  else if (p.D == 80) CD_ATTN(80, 96, 80, 2);  // 640-channel level
+  // d = 40 (SD / LDM 320-channel level): 32-key softmax groups fit 128 VGPRs = four waves per SIMD (2 % faster than
+  // 64-key groups at three: profiles/r2b_attention_v_layouts.txt); CD_ATTN_KG32=0 selects the 64-key form for A/B runs
+  static const bool half_groups = [] { const char* e = getenv("CD_ATTN_KG32"); return !(e && e[0] == '0'); }();
+  if (p.D == 40 && half_groups) CD_ATTN_KG(48, 64, 40, 2, 32);
+  else if (p.D == 40) CD_ATTN(48, 64, 40, 2);
+  else if (p.D == 80 && half_groups) CD_ATTN_KG(80, 96, 80, 2, 32);  // 640-channel level: three waves per SIMD
+  else if (p.D == 80) CD_ATTN(80, 96, 80, 2);
   else if (p.D <= 32) CD_ATTN(32, 32, 0, 2);
   else if (p.D <= 48) CD_ATTN(48, 64, 0, 2);
   else if (p.D <= 64) CD_ATTN(64, 64, 0, 2);

@@ -86,9 +86,9 @@ __device__ inline uint32_t pack2_prob(float lo, float hi) {
   const h2 v = {(_Float16)lo, (_Float16)hi};
   return __builtin_bit_cast(uint32_t, v);
 #else
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+  typedef __attribute__((ext_vector_type(2))) __bf16 b2;  // plain casts: hipcc emits v_cvt_pk_bf16_f32 and pads its
+  const b2 v = {(__bf16)lo, (__bf16)hi};                  // hazards itself (an asm statement would not be padded)
+  return __builtin_bit_cast(uint32_t, v);
 #endif
 }
 #if CD_ACT_FP16

@@ -99,8 +99,12 @@ def _run(cls, fx_name, res, ctx_dim, report):
     assert zn_rel < 2e-3 * FMT, zn_rel
     assert max(eps_rel) < 5e-2 * FMT, eps_rel
     # 99-step self-cycle at full size on a random-init 860 M-parameter network (the fp32 reference closes it to 1.6e-5,
-    # SURVEY.md 8c; a 16-bit engine re-quantises x_t every step)
-    assert cyc.max().item() < 0.15 * FMT, cyc.max().item()
+    # SURVEY.md 8c; a 16-bit engine re-quantises x_t every step). The chain is chaotic in its low bits: over six
+    # builds of round 2 the rms error was 0.017-0.020 (C2) / 0.029-0.032 (C3) of a unit-variance latent, the maximum
+    # over 16 K / 4 K elements 0.11-0.16. The rms is the stable figure and carries the bound (2x); the maximum gets
+    # the same factor.
+    assert cyc.pow(2).mean().sqrt().item() < 0.065 * FMT, cyc.pow(2).mean().sqrt().item()
+    assert cyc.max().item() < 0.32 * FMT, cyc.max().item()
     return p
 
 

@@ -242,7 +242,9 @@ def test_attention(engine, report, case, vt):
     att = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1)
     ref = (att @ vh).transpose(1, 2).reshape(B, Tq, C)
     got = _ops.attention(engine, q, k, v, H, scale, v_transposed=vt)
-    _check(report, "attention/%s/%s" % (name, "vt" if vt else "v"), got, ref, rel=2e-2, mean=1e-2)
+    # measured (fp16 storage): rel_to_max 3-10e-4, mean_rel 3-4e-4; bf16 storage is 8x coarser
+    f = 1.0 if engine.lib.cd_act_format() == 1 else 8.0
+    _check(report, "attention/%s/%s" % (name, "vt" if vt else "v"), got, ref, rel=4e-3 * f, mean=1.5e-3 * f)
 
 
 @pytest.mark.parametrize("vt", [False, True], ids=["v_token_major", "v_transposed"])
@@ -274,7 +276,8 @@ def test_attention_deferred_max(engine, report, case, vt):
     att = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1)
     ref = (att @ vh).transpose(1, 2).reshape(B, Tq, C).float()
     got = _ops.attention(engine, q, k, v, H, scale, v_transposed=vt)
-    _check(report, "attention_deferred_max/%s/%s" % (case, "vt" if vt else "v"), got, ref, rel=2e-2, mean=1e-2)
+    f = 1.0 if engine.lib.cd_act_format() == 1 else 8.0  # measured: rel_to_max 4-10e-4, mean_rel 3-5e-4 (fp16)
+    _check(report, "attention_deferred_max/%s/%s" % (case, "vt" if vt else "v"), got, ref, rel=4e-3 * f, mean=2e-3 * f)
 
 
 def test_softmax_rows(engine, report):
