@@ -96,9 +96,9 @@ __global__ __launch_bounds__(256, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3) : 2)
   }
 
   // ---- staging plan (fixed per thread): K tile [64][DQK] zero padded, V^T tile [DV][64] / V tile [64][VS].
-  // Global reads are buffer loads: a 32-bit per-thread byte offset (kNoLoad = out of range for inactive slots), the
-  // tile's position as the scalar offset, and a descriptor whose size ends at the last valid row - rows beyond Tk
-  // (beyond vt_dpad for V^T) arrive as zeros from the bounds check, without branches or 64-bit address arithmetic.
+  // Global reads are buffer loads: a 32-bit per-thread byte offset (kNoLoad = out of range for inactive slots) plus the
+  // tile's position, and a descriptor whose size ends at the last valid row - rows beyond Tk (beyond vt_dpad for
+  // V^T) arrive as zeros from the bounds check, without branches or 64-bit address arithmetic.
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   constexpr unsigned kNoLoad = 0x80000000u;
   const unsigned k_bytes = p.Tk > 0 ? (unsigned)(((int64_t)(p.Tk - 1) * p.ldk + D) * 2) : 0u;
@@ -135,14 +135,17 @@ __global__ __launch_bounds__(256, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3) : 2)
   }
   uint4 kreg[NKR], vreg[NVR];
   auto fetch = [&](int key0) {
-    const int k_soff = key0 * p.ldk * 2;
-    const int v_soff = VTOK ? key0 * p.ldv * 2 : key0 * 2;
+    // the tile position is ADDED TO THE VECTOR OFFSET (one v_add per load): the hardware bounds check covers the
+    // vector offset only - a scalar offset is excluded from it, and rows beyond Tk of a ragged last tile (cross-
+    // attention: 77 keys) would be read from whatever follows the tensor instead of arriving as zeros
+    const unsigned k_toff = (unsigned)(key0 * p.ldk * 2);
+    const unsigned v_toff = (unsigned)(VTOK ? key0 * p.ldv * 2 : key0 * 2);
 #pragma unroll
     for (int i = 0; i < NKR; ++i)
-      kreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_k, k_voff[i], k_soff, 0));
+      kreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_k, k_voff[i] + k_toff, 0, 0));
 #pragma unroll
     for (int i = 0; i < NVR; ++i)
-      vreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, v_voff[i], v_soff, 0));
+      vreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, v_voff[i] + v_toff, 0, 0));
   };
   // VTOK = false: V^T rows are stored with the four 4-key pieces of every 16-key group in the order [0 2 1 3]: the
   // two pieces a lane feeds to one PV MFMA (keys 4*half.. and 8+4*half.., the accumulator layout of S^T) are then one

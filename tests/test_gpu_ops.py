@@ -280,6 +280,30 @@ def test_attention_deferred_max(engine, report, case, vt):
     _check(report, "attention_deferred_max/%s/%s" % (case, "vt" if vt else "v"), got, ref, rel=4e-3 * f, mean=2e-3 * f)
 
 
+@pytest.mark.parametrize("vt", [False, True], ids=["v_token_major", "v_transposed"])
+def test_attention_ragged_tail_is_zero_filled(engine, report, vt):
+    """Keys beyond Tk in the last 64-key tile must arrive as zeros from the buffer descriptor's bounds check, not as
+    whatever follows the tensor: 77 keys (the cross-attention length), batch of 2, and the SECOND batch element's K / V
+    all NaN - for the first element the rows 77 ... 127 of its ragged tile are exactly those NaN rows if the check does
+    not cover the tile offset (0 * NaN would poison every output of element 0)."""
+    g = torch.Generator().manual_seed(31)
+    B, H, D, Tq, Tk = 2, 8, 40, 128, 77
+    C = H * D
+    q = r16(torch.randn(B, Tq, C, generator=g))
+    k = r16(torch.randn(B, Tk, C, generator=g))
+    v = r16(torch.randn(B, Tk, C, generator=g))
+    k[1] = float("nan")
+    v[1] = float("nan")
+    scale = D ** -0.5
+    qh = q[:1].view(1, Tq, H, D).transpose(1, 2)
+    kh = k[:1].view(1, Tk, H, D).transpose(1, 2)
+    vh = v[:1].view(1, Tk, H, D).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1) @ vh).transpose(1, 2).reshape(1, Tq, C)
+    got = _ops.attention(engine, q, k, v, H, scale, v_transposed=vt)[:1]
+    f = 1.0 if engine.lib.cd_act_format() == 1 else 8.0
+    _check(report, "attention_ragged_tail/%s" % ("vt" if vt else "v"), got, ref, rel=4e-3 * f, mean=1.5e-3 * f)
+
+
 def test_softmax_rows(engine, report):
     g = torch.Generator().manual_seed(19)
     s = torch.randn(70, 1000, generator=g) * 4
