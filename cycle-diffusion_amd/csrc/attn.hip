@@ -99,7 +99,6 @@ __global__ __launch_bounds__(256, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3) : 2)
   // Global reads are buffer loads: a 32-bit per-thread byte offset (kNoLoad = out of range for inactive slots) plus the
   // tile's position, and a descriptor whose size ends at the last valid row - rows beyond Tk (beyond vt_dpad for
   // V^T) arrive as zeros from the bounds check, without branches or 64-bit address arithmetic.
-  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   constexpr unsigned kNoLoad = 0x80000000u;
   const unsigned k_bytes = p.Tk > 0 ? (unsigned)(((int64_t)(p.Tk - 1) * p.ldk + D) * 2) : 0u;
   const unsigned v_bytes = VTOK ? (p.Tk > 0 ? (unsigned)(((int64_t)(p.Tk - 1) * p.ldv + D) * 2) : 0u)
