@@ -15,14 +15,15 @@
 //     8 lanes per 128-byte row segment (EPI = 1), or directly as 8-byte stores (EPI = 0, the pattern DESIGN.md section 7
 //     found slow: for comparison).
 //
-//   hipcc --offload-arch=gfx950 -O3 -o scripts/ubench/lin_areg scripts/ubench/lin_areg.hip
-//   scripts/ubench/lin_areg [M=131072] [N=320] [iters=20]        (K = 320)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o scripts/ubench/lin_areg scripts/ubench/lin_areg.hip
+//   scripts/ubench/lin_areg [M=131072] [N=320] [K=320|640] [iters=20]
 // Prints the check against a CPU reference on sampled rows, then us / launch, TFLOP/s and effective TB/s per variant.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include <vector>
 
 typedef _Float16 half_t;
@@ -37,15 +38,28 @@ typedef __attribute__((address_space(3))) void* lptr_t;
     if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); }      \
   } while (0)
 
-constexpr int K = 320;
-constexpr int NKS = K / 16;         // 16-wide k slices = A fragments per wave
-constexpr int KSH = NKS / 2;        // k slices per piece (the K extent is streamed in two halves)
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+constexpr int KSH = 10;             // k slices (of 16) per piece: a piece is 64 output columns x 160 k
 constexpr int PIECE = 2 * KSH * 1024;  // bytes: 2 column blocks of 32 x KSH slices x 1 KiB
 constexpr int EPI_LD = 72;          // fp16 elements per staged output row (64 + 8 pad: 36 dwords, conflict-free b128)
 
-template <int NSTAGE, int EPI>
+// K = 320 (20 A fragments = 80 VGPRs, 2 pieces per 64-column tile) or 640 (40 fragments = 160 VGPRs, 4 pieces).
+// RESID: out[m][n] += bias-free product, read-modify-write of the same element by the same lane (the in-place
+// residual update of the attention / feed-forward output projections).
+template <int K, int NSTAGE, int EPI, bool RESID>
 __global__ __launch_bounds__(256, 2) void k_lin_areg(const half_t* __restrict__ A, const half_t* __restrict__ W,
                                                      half_t* __restrict__ out, int M, int N) {
+  constexpr int NKS = K / 16;       // 16-wide k slices = A fragments per wave
+  constexpr int NPT = NKS / KSH;    // pieces per 64-column tile
+  static_assert(NKS % KSH == 0, "K must be a multiple of 160");
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem;                                // [NSTAGE][PIECE]
@@ -57,6 +71,7 @@ __global__ __launch_bounds__(256, 2) void k_lin_areg(const half_t* __restrict__ 
   constexpr unsigned kNoLoad = 0x80000000u;
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (unsigned)((size_t)M * K * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (unsigned)((size_t)N * K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (unsigned)((size_t)M * N * 2), 0x00020000);
 
   // ---- A fragments (the MFMA B operand of D^T = W A^T): lane holds A[m][ks*16 + 8*half .. +7] for all 20 slices
   f16x8 af[NKS];
@@ -69,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void k_lin_areg(const half_t* __restrict__ 
 
   // ---- W pieces: piece p = output columns [64 * (p >> 1), +64) x k slices [KSH * (p & 1), +KSH), 20 blocks of 1 KiB:
   // block j = column block j / KSH (32 columns), slice j % KSH; this wave issues blocks wave, wave + 4, ... (5 of them)
-  const int npieces = (N / 64) * 2;
+  const int npieces = (N / 64) * NPT;
   const unsigned w_lane = (unsigned)(((size_t)mi * K + 8 * half) * 2);  // row (lane & 31), k half (lane >> 5)
   // per-wave block geometry (scalar): block j -> byte offset of its W sub-block relative to the piece origin
   unsigned blk_off[5];
@@ -81,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void k_lin_areg(const half_t* __restrict__ 
   auto issue_piece = [&](int p, int slot_idx) {
     // pieces past the end are issued with an out-of-range offset (zero fill into a dead slot): every iteration has
     // the same vmcnt footprint and the loop body is branch-free (scalar select, no control flow)
-    const unsigned origin = p < npieces ? (unsigned)((((p >> 1) * 64) * K + (p & 1) * KSH * 16) * 2) : kNoLoad;
+    const unsigned origin = p < npieces ? (unsigned)((((p / NPT) * 64) * K + (p % NPT) * KSH * 16) * 2) : kNoLoad;
     char* slot = ring + slot_idx * PIECE + wave * 1024;
 #pragma unroll
     for (int u = 0; u < 5; ++u)
@@ -99,16 +114,32 @@ __global__ __launch_bounds__(256, 2) void k_lin_areg(const half_t* __restrict__ 
 
   int cur = 0, nxt = NSTAGE - 1;  // ring slot of piece p / slot the next prefetch goes to (= slot of piece p - 1)
   for (int nt = 0; nt < N / 64; ++nt) {
+    // in-place residual: read at the START of the tile (older than the pieces issued during it), so that waiting for
+    // it in the epilogue does not drain the ring (returns are in order). Same elements, same lane as the store.
+    u32x4 rres[4];
+    if (RESID) {
+      static_assert(!RESID || EPI == 1, "the residual variant uses the LDS epilogue's store mapping");
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {  // compile-time k half: the A fragments are indexed statically (no v_cndmask)
-      const int p = nt * 2 + kh;
+      for (int i = 0; i < 4; ++i) {
+        const int mm = blockIdx.x * 128 + wave * 32 + (lane >> 3) + 8 * i;
+        const unsigned off = mm < M ? (unsigned)(((size_t)mm * N + nt * 64 + (lane & 7) * 8) * 2) : kNoLoad;
+        rres[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_o, off, 0, 0);
+      }
+    }
+    static_for<0, NPT>([&](auto khc) {  // compile-time k part: A fragments and wait counts are indexed statically
+      constexpr int kh = decltype(khc)::value;
+      const int p = nt * NPT + kh;
       // piece p has landed when at most (NSTAGE - 2) younger pieces (5 loads each per wave) are in flight; the A
-      // fragment loads are older than every piece and are covered by the same count. vmcnt counts stores too: the NST
-      // stores of the previous tile's epilogue are younger than every piece issued so far, so after an epilogue the
-      // exact count is that much larger (with the smaller one the wait would also drain most of the prefetched piece)
-      constexpr int NST = EPI ? 4 : 8;
-      if (kh == 0 && nt > 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * 5 + NST) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NSTAGE - 2) * 5) : "memory");
+      // fragment loads are older than every piece and are covered by the same count. vmcnt counts stores too, and
+      // returns are in issue order: the operations issued at the tile boundary (the previous tile's NSTORE stores, this
+      // tile's NRES residual reads) are younger than every piece issued before the boundary, i.e. than the first
+      // NSTAGE - 1 pieces of the tile - for those the exact count is that much larger (a smaller one would still be
+      // correct but would also drain the prefetched pieces)
+      constexpr int NSTORE = EPI ? 4 : 8, NRES = RESID ? 4 : 0;
+      constexpr bool bnd = kh <= NSTAGE - 2;
+      constexpr int cnt0 = (NSTAGE - 2) * 5 + (bnd ? NRES : 0), cnt1 = cnt0 + (bnd ? NSTORE : 0);
+      if (nt > 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(cnt1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(cnt0) : "memory");
       issue_piece(p + NSTAGE - 1, nxt);  // into the slot of piece p - 1: all waves are past the barrier, nobody reads it
       const char* slot = ring + cur * PIECE;
       nxt = cur;
@@ -121,11 +152,10 @@ __global__ __launch_bounds__(256, 2) void k_lin_areg(const half_t* __restrict__ 
           acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, af[kh * KSH + ksl], acc[nb], 0, 0, 0);
         }
       }
-    }
+    });
     {
-      const int p = nt * 2 + 1;
-    // the 64 columns of this tile are complete: lane owns row m, columns (r&3) + 8*(r>>2) + 4*half
-      const int n0 = (p >> 1) * 64;
+      // the 64 columns of this tile are complete: lane owns row m, columns (r&3) + 8*(r>>2) + 4*half
+      const int n0 = nt * 64;
       if (EPI == 0) {
         if (m < M) {
 #pragma unroll
@@ -133,9 +163,10 @@ __global__ __launch_bounds__(256, 2) void k_lin_areg(const half_t* __restrict__ 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               typedef __attribute__((ext_vector_type(4))) _Float16 h4;
-              const h4 v = {(half_t)acc[nb][4 * q], (half_t)acc[nb][4 * q + 1], (half_t)acc[nb][4 * q + 2],
-                            (half_t)acc[nb][4 * q + 3]};
-              *(h4*)(out + (size_t)m * N + n0 + nb * 32 + 8 * q + 4 * half) = v;
+              h4* op = (h4*)(out + (size_t)m * N + n0 + nb * 32 + 8 * q + 4 * half);
+              h4 v = {(half_t)acc[nb][4 * q], (half_t)acc[nb][4 * q + 1], (half_t)acc[nb][4 * q + 2],
+                      (half_t)acc[nb][4 * q + 3]};
+              *op = v;
             }
         }
       } else {
@@ -155,8 +186,18 @@ __global__ __launch_bounds__(256, 2) void k_lin_areg(const half_t* __restrict__ 
         for (int i = 0; i < 4; ++i) {  // 32 rows x 8 chunks of 16 bytes: 8 lanes per 128-byte row segment
           const int row = (lane >> 3) + 8 * i, ch = lane & 7;
           const int mm = blockIdx.x * 128 + wave * 32 + row;
-          const u32x4 v = *(const u32x4*)(st + row * EPI_LD + ch * 8);
-          if (mm < M) *(u32x4*)(out + (size_t)mm * N + n0 + ch * 8) = v;
+          u32x4 v = *(const u32x4*)(st + row * EPI_LD + ch * 8);
+          if (mm < M) {
+            u32x4* op = (u32x4*)(out + (size_t)mm * N + n0 + ch * 8);
+            if (RESID) {  // the staged product was rounded to fp16 once; the sum is rounded again (prototype: timing)
+              const f16x8 a = __builtin_bit_cast(f16x8, v), r = __builtin_bit_cast(f16x8, rres[i]);
+              f16x8 sum;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) sum[e] = (half_t)((float)a[e] + (float)r[e]);
+              v = __builtin_bit_cast(u32x4, sum);
+            }
+            *op = v;
+          }
         }
       }
 #pragma unroll
@@ -169,10 +210,10 @@ __global__ __launch_bounds__(256, 2) void k_lin_areg(const half_t* __restrict__ 
 #endif
 }
 
-template <int NSTAGE, int EPI>
+template <int K, int NSTAGE, int EPI, bool RESID>
 float run(const half_t* A, const half_t* W, half_t* out, int M, int N, int iters) {
   const size_t lds = (size_t)NSTAGE * PIECE + 4 * 32 * EPI_LD * sizeof(half_t);
-  auto kern = k_lin_areg<NSTAGE, EPI>;
+  auto kern = k_lin_areg<K, NSTAGE, EPI, RESID>;
   HIP_OK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const dim3 grid((M + 127) / 128);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, A, W, out, M, N);
@@ -188,11 +229,8 @@ float run(const half_t* A, const half_t* W, half_t* out, int M, int N, int iters
   return ms / iters;
 }
 
-int main(int argc, char** argv) {
-  const int M = argc > 1 ? atoi(argv[1]) : 131072;
-  const int N = argc > 2 ? atoi(argv[2]) : 320;
-  const int iters = argc > 3 ? atoi(argv[3]) : 20;
-  if (N % 64 != 0) { fprintf(stderr, "N must be a multiple of 64\n"); return 1; }
+template <int K>
+int bench(int M, int N, int iters) {
   std::vector<half_t> hA((size_t)M * K), hW((size_t)N * K), hO((size_t)M * N);
   unsigned s = 12345u;
   auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
@@ -203,7 +241,10 @@ int main(int argc, char** argv) {
   HIP_OK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
   const double flop = 2.0 * M * N * K, bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * N);
-  auto check = [&](const char* name) {
+  // the timed launches of a RESID variant keep accumulating into `out`: the check runs on ONE launch from zeros
+  auto check = [&](const char* name, float (*fn)(const half_t*, const half_t*, half_t*, int, int, int)) {
+    HIP_OK(hipMemset(dO, 0, hO.size() * 2));
+    fn(dA, dW, dO, M, N, 0);  // iters = 0: the single untimed launch only
     HIP_OK(hipMemcpy(hO.data(), dO, hO.size() * 2, hipMemcpyDeviceToHost));
     double worst = 0;
     for (int t = 0; t < 96; ++t) {
@@ -215,19 +256,32 @@ int main(int argc, char** argv) {
         if (e > worst) worst = e;
       }
     }
-    printf("%-22s max |err| over 96 sampled rows: %.3e %s\n", name, worst, worst < 2e-2 ? "ok" : "MISMATCH");
+    printf("%-34s max |err| over 96 sampled rows: %.3e %s\n", name, worst, worst < 3e-2 ? "ok" : "MISMATCH");
   };
-  struct V { const char* name; float (*fn)(const half_t*, const half_t*, half_t*, int, int, int); };
-  const V variants[] = {{"3-stage, LDS epilogue", run<3, 1>}, {"3-stage, 8-B stores", run<3, 0>},
-                        {"2-stage, LDS epilogue", run<2, 1>}, {"4-stage, LDS epilogue", run<4, 1>}};
-  printf("out[%d][%d] = A[%d][%d] . W[%d][%d]^T  (%.1f GFLOP, %.0f MB of operands)\n", M, N, M, K, N, K, flop * 1e-9,
-         bytes * 1e-6);
+  struct V { const char* name; float (*fn)(const half_t*, const half_t*, half_t*, int, int, int); bool resid; };
+  const V variants[] = {{"3-stage, LDS epilogue", run<K, 3, 1, false>, false},
+                        {"3-stage, 8-B stores", run<K, 3, 0, false>, false},
+                        {"2-stage, LDS epilogue", run<K, 2, 1, false>, false},
+                        {"4-stage, LDS epilogue", run<K, 4, 1, false>, false},
+                        {"3-stage, LDS epilogue, += out", run<K, 3, 1, true>, true}};
+  printf("out[%d][%d] = A[%d][%d] . W[%d][%d]^T  (%.1f GFLOP, %.0f MB of operands; += out reads the output too)\n", M, N, M,
+         K, N, K, flop * 1e-9, bytes * 1e-6);
   for (const V& v : variants) {
-    HIP_OK(hipMemset(dO, 0, hO.size() * 2));
+    check(v.name, v.fn);
     const float ms = v.fn(dA, dW, dO, M, N, iters);
-    check(v.name);
-    printf("%-22s %8.1f us  %7.1f TFLOP/s  %5.2f TB/s of operand traffic\n", v.name, ms * 1e3, flop / ms * 1e-9,
-           bytes / ms * 1e-9);
+    const double b = bytes + (v.resid ? 2.0 * M * N : 0.0);
+    printf("%-34s %8.1f us  %7.1f TFLOP/s  %5.2f TB/s of operand traffic\n", v.name, ms * 1e3, flop / ms * 1e-9,
+           b / ms * 1e-9);
   }
+  HIP_OK(hipFree(dA)); HIP_OK(hipFree(dW)); HIP_OK(hipFree(dO));
   return 0;
+}
+
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 131072;
+  const int N = argc > 2 ? atoi(argv[2]) : 320;
+  const int Kd = argc > 3 ? atoi(argv[3]) : 320;
+  const int iters = argc > 4 ? atoi(argv[4]) : 20;
+  if (N % 64 != 0 || (Kd != 320 && Kd != 640)) { fprintf(stderr, "N %% 64 == 0, K in {320, 640}\n"); return 1; }
+  return Kd == 320 ? bench<320>(M, N, iters) : bench<640>(M, N, iters);
 }
