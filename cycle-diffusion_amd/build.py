@@ -37,21 +37,22 @@ def _stale(target, deps):
 def build(force=False, verbose=False, variant=None):
     """variant=None: the product library (fp16 storage). variant="bf16": the same sources with -DCD_ACT_FP16=0
     into lib/libcyclediff_bf16.so - only for the measurement-hygiene bench line (CYCLEDIFF_LIB=... python bench.py)."""
-    global OBJDIR, LIB
-    defines = []
+    objdir, lib, defines = OBJDIR, LIB, []
     if variant == "bf16":
-        OBJDIR = os.path.join(HERE, "build", "bf16")
-        LIB = os.path.join(LIBDIR, "libcyclediff_bf16.so")
+        objdir = os.path.join(HERE, "build", "bf16")
+        lib = os.path.join(LIBDIR, "libcyclediff_bf16.so")
         defines = ["-DCD_ACT_FP16=0"]
+    elif variant is not None:
+        raise ValueError("unknown build variant %r" % (variant,))
     os.makedirs(LIBDIR, exist_ok=True)
-    os.makedirs(OBJDIR, exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
     objs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJDIR, s.replace(".hip", ".o"))
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
             extra = ["-ffp-contract=off"] if s == "sched.hip" else []  # scheduler math: reference op order, no FMA
@@ -71,9 +72,9 @@ def build(force=False, verbose=False, variant=None):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    if jobs or force or _stale(lib, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":

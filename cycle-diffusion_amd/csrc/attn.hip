@@ -249,7 +249,9 @@ __global__ __launch_bounds__(256, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3) : 2)
         const float mxq = fmaxf(mx, __shfl_xor(mx, 32));  // both half-lanes of a query agree
         float delta = first ? mxq : fmaxf(mxq, 0.f);
         delta = delta == -INFINITY ? 0.f : delta;
-        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        // on the first group o and l_part are still zero: a reference point at or below -128 (log2 units) would
+        // make exp2(-delta) = +inf and 0 * inf = NaN
+        const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
         for (int kh = 0; kh < HPG; ++kh)
 #pragma unroll

@@ -342,12 +342,12 @@ int cd_unet_forward(cd_handle h, int net, const float* x, const float* t, const 
 
 int cd_text_encode(cd_handle h, int net, const int32_t* tokens, int B, int L, float* out) {
   CD_API_BEGIN
+  CD_CHECK(h, "null handle");
   enter_engine(h);
-  CD_CHECK(h && net >= 0 && net < (int)h->nets.size() &&
+  CD_CHECK(net >= 0 && net < (int)h->nets.size() &&
                (h->nets[net]->kind() == CD_NET_CLIP_TEXT || h->nets[net]->kind() == CD_NET_BERT_XTR),
            "net %d is not a text encoder", net);
   CD_CHECK(tokens && out && B > 0 && L > 0, "bad argument");
-  CD_CHECK(h, "null handle");
   ArenaScope arena_scope(h->arena);
   Ctx c = h->ctx();
   static_cast<TextEncoder*>(h->nets[net].get())->encode(c, (const int*)tokens, B, L, out);
@@ -361,9 +361,9 @@ static TextEncoder* get_tower(cd_handle h, int net, int kind) {
 
 int cd_clip_text_features(cd_handle h, int net, const int32_t* tokens, int B, int L, float* out) {
   CD_API_BEGIN
+  CD_CHECK(h, "null handle");
   enter_engine(h);
   CD_CHECK(tokens && out && B > 0 && L > 0, "bad argument");
-  CD_CHECK(h, "null handle");
   ArenaScope arena_scope(h->arena);
   Ctx c = h->ctx();
   get_tower(h, net, CD_NET_OCLIP_TEXT)->text_features(c, (const int*)tokens, B, L, out);
@@ -372,9 +372,9 @@ int cd_clip_text_features(cd_handle h, int net, const int32_t* tokens, int B, in
 
 int cd_clip_image_features(cd_handle h, int net, const float* img, int B, float* out) {
   CD_API_BEGIN
+  CD_CHECK(h, "null handle");
   enter_engine(h);
   CD_CHECK(img && out && B > 0, "bad argument");
-  CD_CHECK(h, "null handle");
   ArenaScope arena_scope(h->arena);
   Ctx c = h->ctx();
   get_tower(h, net, CD_NET_OCLIP_VISION)->image_features(c, img, B, out);

@@ -1,6 +1,8 @@
 // Small HBM-bound helpers: layout changes at the fp32-NCHW boundary, timestep embeddings, the
 // time-embedding MLP on [B][dim] vectors, pooling / upsampling, VAE posterior sampling.
 #include "common.h"
+#include <mutex>
+
 #include "kernels.h"
 
 namespace cd {
@@ -351,11 +353,10 @@ void launch_vq_quantize(hipStream_t st, const float* z, float in_mul, const floa
   CD_CHECK(zc >= 1 && zc <= 8 && n_embed > 0, "vq_quantize: embed_dim %d / n_embed %d", zc, n_embed);
   const size_t lds = (size_t)n_embed * zc * sizeof(float);
   CD_CHECK(lds <= 150 * 1024, "vq_quantize: codebook of %zu bytes does not fit LDS", lds);
-  static bool attr = false;
-  if (!attr) {
+  static std::once_flag attr_once;  // engines on several host threads may reach this launch together
+  std::call_once(attr_once, [&]() {
     HIP_CHECK(hipFuncSetAttribute((const void*)k_vq_quantize, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr = true;
-  }
+  });
   const int64_t n = (int64_t)B * HW;
   int grid = (int)((n + 255) / 256);
   if (grid > 512) grid = 512;

@@ -49,11 +49,17 @@ class DDPMDDIMWrapper(torch.nn.Module):
 
     def __init__(self, source_model_type, sample_type, custom_steps, es_steps, source_model_path=None,
                  refine_steps=0, refine_iterations=1, eta=None, t_0=None, enforce_class_input=None, device=None,
-                 noise_on_cpu=False, precision="fp32", net_desc=None):
+                 noise_on_cpu=False, precision="fp32", net_desc=None, allow_lossy_ddim=False):
         super().__init__()
         if str(precision) not in PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
         self.precision = str(precision)
+        if PRECISIONS[self.precision] == _ffi.CD_PREC_16 and sample_type == "ddim" and not allow_lossy_ddim:
+            # the 'ddim' chain rescales x by up to x130 end to end; a 16-bit quantiser inside the network
+            # turns it into a ~15 dB reconstruction. Known-broken, so refuse unless asked for by name (bench.py's
+            # throughput-only `--precision fp16` line does).
+            raise ValueError("precision=%r with sample_type='ddim' does not reproduce the reference (about 15 dB); use "
+                             "precision='fp32' (default) or pass allow_lossy_ddim=True" % self.precision)
         # parity runs draw every noise tensor on the CPU, one tensor per reference draw, in the reference's order
         self.noise_on_cpu = bool(noise_on_cpu)
         self.enforce_class_input = enforce_class_input

@@ -17,13 +17,16 @@ import torch
 
 from .. import _ffi, schedule
 from ..engine import ldm_uncond_unet_desc, vq_f4_vae_desc
-from ..runtime import get_engine, load_or_init_weights
+from ..runtime import apply_ema_shadow, get_engine, load_or_init_weights, read_checkpoint
 
-# source_model_type -> (U-Net descriptor, first-stage descriptor, linear_start, linear_end, scale_factor) from
-# model/lib/latentdiff/models/ldm/<type>/config.yaml
+# source_model_type -> (U-Net descriptor, first-stage descriptor, linear_start, linear_end, scale_factor, use_ema)
+# from model/lib/latentdiff/models/ldm/<type>/config.yaml. Neither config sets `use_ema`, so DDPM's default True
+# holds (latentdiff ddpm.py:55,88-91) and every sampler call of the reference wrapper runs inside
+# `model.ema_scope("Plotting")` (latentdiff_stochastic_wrapper.py:116,135,155,164): the U-Net is evaluated on the
+# EMA shadow weights `model_ema.*`, not on `model.diffusion_model.*`.
 MODEL_TYPES = {
-    "celeba256": (ldm_uncond_unet_desc, vq_f4_vae_desc, 0.0015, 0.0195, 1.0),
-    "ffhq256": (ldm_uncond_unet_desc, vq_f4_vae_desc, 0.0015, 0.0195, 1.0),
+    "celeba256": (ldm_uncond_unet_desc, vq_f4_vae_desc, 0.0015, 0.0195, 1.0, True),
+    "ffhq256": (ldm_uncond_unet_desc, vq_f4_vae_desc, 0.0015, 0.0195, 1.0, True),
 }
 
 
@@ -31,7 +34,7 @@ class LatentDiffStochasticWrapper(torch.nn.Module):
 
     def __init__(self, source_model_type, custom_steps, eta, white_box_steps, refine_steps=0,
                  enforce_class_input=None, unconditional_guidance_scale=None, device=None, noise_on_cpu=False,
-                 unet_desc=None, vae_desc=None):
+                 unet_desc=None, vae_desc=None, state_dict=None):
         super().__init__()
         if enforce_class_input:
             raise NotImplementedError("class-conditional LDMs (cin256) are not used by the reference configs")
@@ -43,7 +46,7 @@ class LatentDiffStochasticWrapper(torch.nn.Module):
         self.noise_on_cpu = bool(noise_on_cpu)
         if source_model_type not in MODEL_TYPES:
             raise NotImplementedError(source_model_type)
-        udesc_fn, vdesc_fn, ls, le, self.scale_factor = MODEL_TYPES[source_model_type]
+        udesc_fn, vdesc_fn, ls, le, self.scale_factor, self.use_ema = MODEL_TYPES[source_model_type]
         self.engine = get_engine(device)
         udesc = unet_desc if unet_desc is not None else udesc_fn()
         vdesc = vae_desc if vae_desc is not None else vdesc_fn()
@@ -52,8 +55,11 @@ class LatentDiffStochasticWrapper(torch.nn.Module):
         self.vae = self.engine.create_net(vdesc)
         self.vae_factor = 2 ** (vdesc.n_mult - 1)
         ckpt = os.path.join("ckpts", "ldm_models", "ldm", source_model_type, "model.ckpt")  # prepare_latentdiff (:16)
+        sd = state_dict if state_dict is not None else read_checkpoint(ckpt)
+        if sd is not None and self.use_ema:
+            sd = apply_ema_shadow(sd)
         self.weights_origin = load_or_init_weights(self.engine, ckpt, {
-            self.unet: "model.diffusion_model.", self.vae: "first_stage_model."})
+            self.unet: "model.diffusion_model.", self.vae: "first_stage_model."}, state_dict=sd)
         self.resolution = self.image_size * self.vae_factor
         self.latent_dim = self.image_size ** 2 * self.channels * self.white_box_steps
         self.alphas_cumprod = schedule.latent_alphas_cumprod(1000, ls, le)

@@ -36,6 +36,28 @@ def read_checkpoint(ckpt_path):
     return sd
 
 
+def apply_ema_shadow(sd, model_prefix="model.", ema_prefix="model_ema."):
+    """What `with model.ema_scope():` does to the weights the samplers see (ddpm.py:171-185 -> LitEma.copy_to,
+    ldm/modules/ema.py:46-53): every parameter `<model_prefix><name>` is replaced by the shadow buffer
+    `<ema_prefix><name with the dots removed>` (ema.py:17-21). Models whose config leaves `use_ema` at its default
+    True (celeba256 / ffhq256) are evaluated on the shadow weights. A checkpoint without shadow buffers raises:
+    the reference would silently run on the random-init clones LitEma took at construction."""
+    shadow = {k: v for k, v in sd.items() if k.startswith(ema_prefix)}
+    if not any(k not in (ema_prefix + "decay", ema_prefix + "num_updates") for k in shadow):
+        raise KeyError("use_ema model, but the checkpoint holds no %s* shadow weights" % ema_prefix)
+    out = dict(sd)
+    n = 0
+    for k in sd:
+        if k.startswith(model_prefix) and not k.startswith(ema_prefix):
+            s = ema_prefix + k[len(model_prefix):].replace(".", "")
+            if s in shadow:
+                out[k] = shadow[s]
+                n += 1
+    if n == 0:
+        raise KeyError("no %s* parameter has a shadow buffer under %s*" % (model_prefix, ema_prefix))
+    return out
+
+
 def synthetic_allowed():
     return os.environ.get("CYCLEDIFF_SYNTHETIC_WEIGHTS", "0") == "1"
 

@@ -2,6 +2,7 @@
 
   python -m oracle.gen_golden_full --only c2      (~25 min on 8 cores)
   python -m oracle.gen_golden_full --only c3      (~6 min)
+  python -m oracle.gen_golden_full --only c5r     (~8 min; BASELINE config 5 at its real size, reduced chain)
 
 One (image, source-text, target-text) triplet per BASELINE configuration, run the way the reference's
 text wrapper composes it (stable_diffusion_stochastic_text_wrapper.py:169-249): VAE encode -> posterior
@@ -27,7 +28,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import ref_import  # noqa: E402
-from oracle.gen_golden import RefVAE, build_ref_sd_unet, load_synth, rnd, save  # noqa: E402
+from oracle.gen_golden import (RefVAE, build_ref_pixel_wrapper, build_ref_sd_unet, load_synth, rnd,  # noqa: E402
+                               save)
 
 FULL_VAE = dict(ch=128, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=[], in_channels=3,
                 resolution=256, z_channels=4, double_z=True, dropout=0.0)
@@ -88,10 +90,49 @@ def gen_c3():
     run_text_triplet("c3_ldm256_e2e", LDM_UNET, 256, 1280, sample_posterior=False)
 
 
+def gen_c5r():
+    """BASELINE config 5 at its real size: two `i_DDPM('AFHQ')` networks (improved_ddpm/script_util.py:5-22,102-104)
+    at 256 x 256, source encodes and target decodes exactly as UnsupervisedTranslation.forward composes them
+    (model/unsupervised_translation.py:49-50): z = source.encode(image) (ddpm_ddim_wrapper.py:455-534), img =
+    target(z) (:392-453, 536-542), sample_type 'ddim', eta 0.1, REDUCED chain custom_steps 100 / es_steps 85 /
+    refine_steps 10 (translate_afhqcat256_to_afhqdog256_ddim_eta01.cfg:10-14 divided by 10), batch 1. One global
+    generator seed before encode (the draws of encode, generate's last step and the refinement loop follow in the
+    reference's own order). The unrefined image (refine_steps 0, fresh seed) is stored beside it."""
+    ref_import.setup()
+    from model.lib.ddpm_ddim.models.improved_ddpm.script_util import i_DDPM
+    seeds = dict(source=201, target=202, image=13, noise=8642, noise_unrefined=97531)
+    t0 = time.time()
+    with torch.no_grad():
+        src, tgt = i_DDPM("AFHQ"), i_DDPM("AFHQ")
+        ns, _ = load_synth(src, seeds["source"])
+        nt, _ = load_synth(tgt, seeds["target"])
+        assert ns == nt
+        ws = build_ref_pixel_wrapper(src, custom_steps=100, es_steps=85, eta=0.1, refine_steps=10, resolution=256)
+        wt = build_ref_pixel_wrapper(tgt, custom_steps=100, es_steps=85, eta=0.1, refine_steps=10, resolution=256)
+        # learn_sigma stays False as the reference sets it for AFHQ (ddpm_ddim_wrapper.py:370-374): the 6-channel
+        # output is split by the shape test (:236-238, :131-134) and the variance half is dropped
+        img = torch.rand((1, 3, 256, 256), generator=torch.Generator().manual_seed(seeds["image"]))
+        torch.manual_seed(seeds["noise"])
+        with ref_import.quiet():
+            z = ws.encode(image=img)
+            print("c5r encode done", time.time() - t0, flush=True)
+            out = wt(z=z)
+            print("c5r decode + refine done", time.time() - t0, flush=True)
+            wt.refine_steps = 0
+            torch.manual_seed(seeds["noise_unrefined"])
+            out0 = wt(z=z)
+        z5 = z.view(1, 85, 3, 256, 256)
+        slots = [0, 1, 42, 84]
+    save("c5r_afhq256_e2e", names=json.dumps(ns), seeds=json.dumps(seeds), custom_steps=100, es_steps=85,
+         refine_steps=10, eta=0.1, z_sub=z5[:, slots], z_sub_slots=np.asarray(slots),
+         z_norms=z5.flatten(2).norm(dim=2), img=out, img_unrefined=out0, cpu_seconds=time.time() - t0,
+         cpu_threads=torch.get_num_threads())
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    for k, fn in dict(c3=gen_c3, c2=gen_c2).items():
+    for k, fn in dict(c3=gen_c3, c2=gen_c2, c5r=gen_c5r).items():
         if not a.only or a.only == k:
             fn()

@@ -48,6 +48,17 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _reference_stubs_do_not_leak():
+    """oracle.ref_import.setup() puts stub `torchvision` / `omegaconf` packages and the reference's own modules into
+    sys.modules; they are removed after every test module so that test order does not matter (a stub torchvision
+    breaks any later `import transformers`)."""
+    yield
+    ri = sys.modules.get("oracle.ref_import")
+    if ri is not None and getattr(ri, "_done", False):
+        ri.teardown()
+
+
 @pytest.fixture(scope="session")
 def engine():
     import cycle_diffusion_amd as cda

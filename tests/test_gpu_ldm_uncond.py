@@ -99,3 +99,27 @@ def test_latentdiff_stochastic_wrapper_vs_reference(report):
     # swaps its codebook row and changes a 4 x 4 pixel patch, so the floor is looser than for the KL first stage
     # (measured 29.4 dB without / 52.2 dB with refinement on this 256-row codebook)
     assert p0 >= 24.0 and p1 >= 24.0, (p0, p1)
+
+
+def test_ema_shadow_weights_are_what_the_unet_runs_on():
+    """A pl-style checkpoint whose EMA shadow differs from the raw U-Net weights: the wrapper must evaluate the
+    shadow (use_ema defaults to True for celeba256 / ffhq256; latentdiff_stochastic_wrapper.py:116-164)."""
+    fx = gu.load("ldm_uncond_tiny")
+    usd = nets.synth_state_dict(json.loads(str(fx["unet_names"])), int(fx["useed"]))
+    vsd = nets.synth_state_dict(json.loads(str(fx["vae_names"])), int(fx["vseed"]))
+    ckpt = {"first_stage_model." + k: v for k, v in vsd.items()}
+    for k, v in usd.items():
+        ckpt["model.diffusion_model." + k] = torch.zeros_like(v)  # raw weights: all zero (eps would be 0)
+        ckpt["model_ema." + ("diffusion_model." + k).replace(".", "")] = v
+    ckpt["model_ema.decay"], ckpt["model_ema.num_updates"] = torch.tensor(0.9999), torch.tensor(1)
+    kw = dict(custom_steps=int(fx["steps"]), eta=0.1, white_box_steps=int(fx["steps"]) + 1, noise_on_cpu=True,
+              unet_desc=tiny_uncond_unet_desc(), vae_desc=tiny_vq_desc())
+    w_ema = LatentDiffStochasticWrapper("celeba256", state_dict=ckpt, **kw)
+    w_ref, _ = _wrapper(fx, 0)
+    x = gu.rnd((1, 3, 16, 16), 5).cuda()
+    t = torch.tensor([500], dtype=torch.int64).cuda()
+    a, b = w_ema.engine.unet_forward(w_ema.unet, x, t), w_ref.engine.unet_forward(w_ref.unet, x, t)
+    assert torch.equal(a, b) and float(a.abs().max()) > 0
+    with pytest.raises(KeyError):
+        LatentDiffStochasticWrapper("celeba256", state_dict={k: v for k, v in ckpt.items()
+                                                            if not k.startswith("model_ema.")}, **kw)

@@ -87,3 +87,36 @@ def test_wrappers_refuse_to_run_without_a_gpu():
     from cycle_diffusion_amd.gan_wrapper.ddpm_ddim_wrapper import DDPMDDIMWrapper
     with pytest.raises(_ffi.EngineError):
         DDPMDDIMWrapper(source_model_type="toy32", sample_type="ddpm", custom_steps=4, es_steps=4)
+
+
+def test_ema_shadow_replaces_the_raw_unet_weights():
+    """celeba256 / ffhq256 leave use_ema at True: the reference samples inside model.ema_scope(), i.e. on the
+    shadow buffers `model_ema.<name without dots>` (ldm/modules/ema.py:17-21,46-53)."""
+    from cycle_diffusion_amd.runtime import apply_ema_shadow
+    raw = {"model.diffusion_model.input_blocks.0.0.weight": torch.zeros(2), "model.diffusion_model.out.2.bias": torch.zeros(3),
+           "first_stage_model.encoder.conv_in.weight": torch.full((1,), 7.0)}
+    sd = dict(raw)
+    sd["model_ema.diffusion_modelinput_blocks00weight"] = torch.ones(2)
+    sd["model_ema.diffusion_modelout2bias"] = torch.full((3,), 2.0)
+    sd["model_ema.decay"], sd["model_ema.num_updates"] = torch.tensor(0.9999), torch.tensor(5)
+    out = apply_ema_shadow(sd)
+    assert torch.equal(out["model.diffusion_model.input_blocks.0.0.weight"], torch.ones(2))
+    assert torch.equal(out["model.diffusion_model.out.2.bias"], torch.full((3,), 2.0))
+    assert torch.equal(out["first_stage_model.encoder.conv_in.weight"], torch.full((1,), 7.0))  # first stage untouched
+    assert torch.equal(sd["model.diffusion_model.out.2.bias"], torch.zeros(3))  # the input dict is not modified
+    with pytest.raises(KeyError):
+        apply_ema_shadow(raw)  # no shadow weights: the reference would sample from random-init clones
+    with pytest.raises(KeyError):
+        apply_ema_shadow(dict(raw, **{"model_ema.decay": torch.tensor(0.9)}))
+
+
+def test_16_bit_ddim_is_refused_by_name():
+    """a 16-bit network inside the pixel 'ddim' chain reproduces the reference to ~15 dB only; the wrapper
+    refuses the combination instead of accepting it silently (the check precedes engine creation: no GPU needed)."""
+    from cycle_diffusion_amd.gan_wrapper.ddpm_ddim_wrapper import DDPMDDIMWrapper
+    with pytest.raises(ValueError, match="allow_lossy_ddim"):
+        DDPMDDIMWrapper(source_model_type="toy32", sample_type="ddim", eta=0.1, custom_steps=4, es_steps=4,
+                        precision="fp16")
+    with pytest.raises(ValueError, match="precision must be"):
+        DDPMDDIMWrapper(source_model_type="toy32", sample_type="ddim", eta=0.1, custom_steps=4, es_steps=4,
+                        precision="fp8")
