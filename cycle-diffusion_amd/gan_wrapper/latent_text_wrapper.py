@@ -67,6 +67,7 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
         # parity runs draw every noise tensor on the CPU in the reference's order; throughput
         # runs draw on the device
         self.noise_on_cpu, self.fold_ensemble = bool(noise_on_cpu), bool(fold_ensemble)
+        self.noise_source = None
         self.engine = get_engine(device)
         udesc = self.UNET_DESC()
         self.channels, self.image_size = udesc.in_channels, udesc.image_size
@@ -124,8 +125,12 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
     def _schedule(self):
         return schedule.DDIMSchedule(self.alphas_cumprod, self.custom_steps, self.eta)
 
-    def _randn(self, shape):
-        if self.noise_on_cpu:
+    def _randn(self, shape, cpu=None):
+        """One noise draw. `noise_source` (a callable shape -> CPU tensor; parity tests) replaces the generator: it lets
+        a test hand every sample of a batch its own stream, e.g. the stream a fixture was made with."""
+        if self.noise_source is not None:
+            return self.noise_source(tuple(shape)).to(self.device, torch.float32)
+        if self.noise_on_cpu if cpu is None else cpu:
             return torch.randn(shape).to(self.device)
         return torch.randn(shape, device=self.device)
 
@@ -151,7 +156,7 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
         if self.SAMPLE_POSTERIOR:
             # DiagonalGaussianDistribution.sample draws on the CPU and moves (distributions.py:36)
             h = self.resolution // self.vae_factor
-            noise = torch.randn((bsz, self.channels, h, h)).to(self.device)
+            noise = self._randn((bsz, self.channels, h, h), cpu=True)
         x0 = self.engine.vae_encode(self.vae, image, noise=noise, sample=self.SAMPLE_POSTERIOR,
                                     scale=self.SCALE_FACTOR)
         sch = self._schedule()
@@ -166,7 +171,7 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
                     K = len(sch) - skip
                     n_loop = min(K, self.white_box_steps - skip - 1) if self.white_box_steps != -1 else 0
                     assert n_loop == K, "white_box_steps shorter than the chain is not used by the reference configs"
-                    if self.noise_on_cpu:
+                    if self.noise_on_cpu or self.noise_source is not None:
                         nz = torch.stack([self._randn(tuple(x0.shape)) for _ in range(K)], 0)
                     else:
                         nz = self._randn((K,) + tuple(x0.shape))

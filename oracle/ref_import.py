@@ -96,8 +96,9 @@ def teardown():
     global _done
     roots = (os.path.join(REF, ""),)
     for name, mod in list(sys.modules.items()):
-        f = getattr(mod, "__file__", None) or ""
-        if getattr(mod, "_cyclediff_stub", False) or f.startswith(roots):
+        d = getattr(mod, "__dict__", None) or {}  # no getattr on the module: lazy packages import on attribute access
+        f = d.get("__file__") or ""
+        if d.get("_cyclediff_stub", False) or (isinstance(f, str) and f.startswith(roots)):
             del sys.modules[name]
     for p in (os.path.join(REF, "model", "lib", "stable_diffusion"), REF):
         while p in sys.path:
