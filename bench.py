@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="image triplets per GPU per step (default: the workload's "
                     "BASELINE batch: 4 for C2, README.md:153; 16 for C3, README.md:195)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-batch", action="store_true", help="skip the extra launch-sets-of-one-step measurement")
+    ap.add_argument("--single-steps", type=int, default=2, help="steps of the single-batch measurement (c2 default run)")
     ap.add_argument("--coalesce", type=int, default=0,
                     help="steps folded into one engine launch set (same images in flight as that many replicas, ONE "
                          "copy of the weights, that many times the rows per GEMM); 1 = one launch set per step; "
@@ -220,13 +222,16 @@ def main():
     R = wl["res"]
     lo, hi = shard_range(B * world, world, rank)
     g = torch.Generator().manual_seed(1)
-    images = torch.rand(B * world, 3, R, R, generator=g)[lo:hi].to(dev)
+    # C distinct global batches (one per step of a launch set): a folded launch set holds C * B DIFFERENT triplets
+    images = torch.rand(C, B * world, 3, R, R, generator=g)[:, lo:hi].to(dev)
     sample_id = torch.arange(lo, hi, device=dev)
-    src = ["source prompt %d" % i for i in range(lo, hi)]
-    tgt = ["target prompt %d" % i for i in range(lo, hi)]
+    src = [["source prompt %d of step %d" % (i, j) for i in range(lo, hi)] for j in range(C)]
+    tgt = [["target prompt %d of step %d" % (i, j) for i in range(lo, hi)] for j in range(C)]
     torch.manual_seed(4 + rank)  # per-rank noise streams
     # launch sets: K steps are issued C at a time (the last set may be smaller)
-    folded = {n: (images.repeat(n, 1, 1, 1), sample_id.repeat(n), src * n, tgt * n) for n in {C, a.steps % C} if n}
+    single = (not a.no_single_batch) and C > 1 and a.workload == "c2"
+    folded = {n: (images[:n].reshape(n * (hi - lo), 3, R, R), sample_id.repeat(n), sum(src[:n], []), sum(tgt[:n], []))
+              for n in {C, a.steps % C, 1 if single else 0} if n}
 
     def compute(r, n):
         """one launch set of n steps (n * B triplets) on replica r"""
@@ -256,6 +261,8 @@ def main():
         return run_in_flight(len(sizes), n_rep, lambda r, i: compute(r, sizes[i]), gather, pass_index=True)
 
     def sync():
+        for _st, m in replicas:  # sleep until the engines' streams are idle (cd_engine_synchronize), then the device
+            (getattr(m, "gan_wrapper", None) or m.source_gan_wrapper).engine.synchronize()
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -284,6 +291,22 @@ def main():
         dt = float(tt.item())
     assert torch.isfinite(out[0][1]).all()
 
+    # BASELINE's literal operating point beside the folded one: launch sets of ONE step (a batch of B triplets per
+    # engine call, B' = B through the DPM-Encoder), timed the same way on every rank
+    single_dt = None
+    if single:
+        gather(0, compute(0, 1))
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(a.single_steps):
+            gather(0, compute(0, 1))
+        sync()
+        single_dt = time.perf_counter() - t1
+        if dist.is_initialized():
+            tt = torch.tensor([single_dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            single_dt = float(tt.item())
+
     res = None
     # roofline of the dominant kernel (implicit-GEMM conv / GEMM family): one more launch set (all ranks take part in
     # its gathers) with per-launch HIP events on rank 0's engine stream; achieved = sum(2*M*N*K) / sum(durations)
@@ -309,7 +332,9 @@ def main():
                        "parallelism": "dp%d" % world, "steps_per_launch_set": C, "launch_sets_in_flight_per_gpu": n_rep,
                        "images_in_flight_per_gpu": B * C * n_rep,
                        "distributed": "nccl(RCCL) process group" if dist.is_initialized() else "single process",
-                       "host_cpu_cores_used": host_cpu / dt,  # ~1: one launching thread (it spin-waits in stream syncs)
+                       # CPU seconds of this rank (all threads) per wall second of the timed region: the launching thread
+                       # sleeps in blocking-sync events (engine step pacing, cd_engine_synchronize)
+                       "host_cpu_cores_used": host_cpu / dt,
                        "storage": ("fp32 activations / weights, v_mfma_f32_32x32x2_f32 (the reference's arithmetic)" if f32
                                    else "%s activations / weights, fp32 accumulate (BASELINE.json's C2 line says bf16: same "
                                         "width and MFMA rate; fp16 keeps the DPM-Encoder's 1/sigma amplification 8x smaller, "
@@ -324,6 +349,12 @@ def main():
                          "algorithmic_tflop_per_step": k_flops / 1e12 / C,
                          "whole_path_frac": ips * wl["flop_per_image"] / 1e12 / (world * peak)},
         }
+        if single_dt is not None:
+            sv = a.single_steps * B * world / single_dt
+            res["single_batch_value"] = sv  # images/s with ONE batch of B per launch set (`--coalesce 1`)
+            res["single_batch"] = {"value": sv, "unit": "images/s", "steps": a.single_steps,
+                                   "ms_per_step": 1e3 * single_dt / a.single_steps, "images_in_flight_per_gpu": B,
+                                   "whole_path_frac": sv * wl["flop_per_image"] / 1e12 / (world * peak)}
         if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
             res["cpu_baseline"] = cpu_baseline(eng, wrapper.unet, wrapper.vae)
         print(json.dumps(res), flush=True)

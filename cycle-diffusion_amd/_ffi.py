@@ -51,6 +51,7 @@ SIGNATURES = {
     "cd_act_format": [],
     "cd_engine_create": [_VP, _SZ, C.POINTER(_VP)],
     "cd_engine_destroy": [_VP],
+    "cd_engine_synchronize": [_VP],
     "cd_engine_workspace_high_water": [_VP, C.POINTER(_SZ)],
     "cd_prof_enable": [_VP, _I],
     "cd_prof_collect": [_VP, C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(C.c_double)],

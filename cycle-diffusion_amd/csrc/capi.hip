@@ -9,8 +9,57 @@
 
 using namespace cd;
 
+// Host pacing (one process per GPU, one launching thread per engine): the sampler loops enqueue ~350 kernels per step
+// and would otherwise run seconds ahead of the GPU, where the HIP runtime busy-waits for queue slots (round 2 measured
+// 2.0 host cores per rank). After every sampler step an event is recorded; the host then SLEEPS (blocking-sync event)
+// until the step kAhead steps back has finished - the GPU always has two whole steps (tens of ms) queued.
+struct StepPacer {
+  static constexpr int kAhead = 2, kRing = kAhead + 1;
+  hipEvent_t ev[kRing] = {nullptr, nullptr, nullptr};
+  long n = 0;
+  bool enabled = true;
+  void init() {
+    const char* e = getenv("CYCLEDIFF_HOST_PACING");
+    enabled = !(e && e[0] == '0');
+    for (auto& x : ev) HIP_CHECK(hipEventCreateWithFlags(&x, hipEventBlockingSync | hipEventDisableTiming));
+  }
+  void tick(hipStream_t st) {
+    if (!enabled) return;
+    HIP_CHECK(hipEventRecord(ev[n % kRing], st));
+    ++n;
+    if (n > kAhead) HIP_CHECK(hipEventSynchronize(ev[(n - 1 - kAhead) % kRing]));
+  }
+  void wait_all(hipStream_t st) {  // blocking (sleeping) equivalent of hipStreamSynchronize
+    if (!ev[0]) { HIP_CHECK(hipStreamSynchronize(st)); return; }
+    HIP_CHECK(hipEventRecord(ev[n % kRing], st));
+    HIP_CHECK(hipEventSynchronize(ev[n % kRing]));
+    ++n;
+  }
+  void destroy() { for (auto& x : ev) if (x) { (void)hipEventDestroy(x); x = nullptr; } }
+};
+
+// Scheduler tables travel through a small ring of pinned host slots: the copy is asynchronous (no stream drain at the
+// start of every sampler call) and the caller may free its table as soon as the entry point returns.
+struct CoefStaging {
+  static constexpr int kSlots = 4;
+  static constexpr size_t kSlotBytes = 64 << 10;
+  char* host = nullptr;
+  hipEvent_t done[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+  int next = 0;
+  void init() {
+    HIP_CHECK(hipHostMalloc((void**)&host, kSlots * kSlotBytes, hipHostMallocDefault));
+    for (auto& x : done) HIP_CHECK(hipEventCreateWithFlags(&x, hipEventBlockingSync | hipEventDisableTiming));
+  }
+  void destroy() {
+    for (auto& x : done) if (x) { (void)hipEventDestroy(x); x = nullptr; }
+    if (host) { (void)hipHostFree(host); host = nullptr; }
+  }
+};
+
 struct cd_engine {
   hipStream_t st = nullptr;
+  StepPacer pacer;
+  CoefStaging coef_staging;
   Arena arena;
   bf16_t* zeros = nullptr;
   float* gn_partial = nullptr;
@@ -111,6 +160,8 @@ int cd_engine_create(void* hip_stream, size_t workspace_bytes, cd_handle* out) {
   HIP_CHECK(hipDeviceSynchronize());
   h->gn_partial_floats = (size_t)1 << 20;
   HIP_CHECK(hipMalloc((void**)&h->gn_partial, h->gn_partial_floats * sizeof(float)));
+  h->pacer.init();
+  h->coef_staging.init();
   *out = h.release();
   CD_API_END
 }
@@ -126,8 +177,17 @@ int cd_engine_destroy(cd_handle h) {
     if (h->splitk.flags) (void)hipFree(h->splitk.flags);
     if (h->zeros) (void)hipFree(h->zeros);
     if (h->gn_partial) (void)hipFree(h->gn_partial);
+    h->pacer.destroy();
+    h->coef_staging.destroy();
     delete h;
   }
+  CD_API_END
+}
+
+int cd_engine_synchronize(cd_handle h) {
+  CD_API_BEGIN
+  CD_CHECK(h, "null handle");
+  h->pacer.wait_all(h->st);
   CD_API_END
 }
 
@@ -252,9 +312,21 @@ Guidance resolve_guidance(const float* ctx_c, const float* ctx_uc, float g) {
 
 StepCoef* upload_coef(cd_engine* h, const cd_step_coef* host, int n) {
   static_assert(sizeof(cd_step_coef) == sizeof(StepCoef), "coef ABI");
-  StepCoef* d = (StepCoef*)h->arena.alloc((size_t)n * sizeof(StepCoef));
-  HIP_CHECK(hipMemcpyAsync(d, host, (size_t)n * sizeof(StepCoef), hipMemcpyHostToDevice, h->st));
-  HIP_CHECK(hipStreamSynchronize(h->st));  // host table may be freed by the caller right after return
+  const size_t bytes = (size_t)n * sizeof(StepCoef);
+  StepCoef* d = (StepCoef*)h->arena.alloc(bytes);
+  CoefStaging& cs = h->coef_staging;
+  if (cs.host && bytes <= CoefStaging::kSlotBytes) {
+    const int slot = cs.next;
+    cs.next = (cs.next + 1) % CoefStaging::kSlots;
+    HIP_CHECK(hipEventSynchronize(cs.done[slot]));  // the copy that last used this slot (a never-recorded event is done)
+    char* stage = cs.host + (size_t)slot * CoefStaging::kSlotBytes;
+    memcpy(stage, host, bytes);
+    HIP_CHECK(hipMemcpyAsync(d, stage, bytes, hipMemcpyHostToDevice, h->st));
+    HIP_CHECK(hipEventRecord(cs.done[slot], h->st));
+  } else {
+    HIP_CHECK(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, h->st));
+    HIP_CHECK(hipStreamSynchronize(h->st));  // host table may be freed by the caller right after return
+  }
   return d;
 }
 
@@ -442,6 +514,7 @@ int cd_dpm_encode(cd_handle h, int net, int sched_kind, const float* x0, const f
     const float* nz = (noise && !is_last) ? noise + (int64_t)(1 + i) * n : nullptr;
     launch_encode_step(h->st, sched_kind, x0, s.xt, s.ehv, nz, seed, (uint32_t)(1 + i), z_out + (1 + i) * chw,
                        zbs, B, s.C, s.HW, s.tab, nullptr, k, is_last, s.xin16(), s.cpad, s.cfg ? 1 : 0);
+    h->pacer.tick(h->st);
   }
   CD_API_END
 }
@@ -467,6 +540,7 @@ int cd_ddim_decode(cd_handle h, int net, int sched_kind, const float* z, int z_s
     const float* nz = (!eps && noise_tail) ? noise_tail + (int64_t)(i - n_eps) * n : nullptr;
     launch_decode_step(h->st, sched_kind, s.xt, s.ehv, eps, zbs, nz, seed, (uint32_t)(0x1000 + i), B, s.C,
                        s.HW, s.tab, nullptr, k, s.xin16(), s.cpad, s.cfg ? 1 : 0, nullptr);
+    h->pacer.tick(h->st);
   }
   HIP_CHECK(hipMemcpyAsync(x_out, s.xt, (size_t)n * 4, hipMemcpyDeviceToDevice, h->st));
   CD_API_END
@@ -488,6 +562,7 @@ int cd_pix_refine(cd_handle h, int net, int sched_kind, float* x, int B, int R, 
     const float* nz = noise ? noise + (int64_t)(1 + i) * n : nullptr;
     launch_decode_step(h->st, sched_kind, s.xt, s.ehv, nullptr, 0, nz, seed, (uint32_t)(0x2001 + i), B, s.C,
                        s.HW, s.tab, nullptr, k, s.xin16(), s.cpad, 0, nullptr);
+    h->pacer.tick(h->st);
   }
   HIP_CHECK(hipMemcpyAsync(x, s.xt, (size_t)n * 4, hipMemcpyDeviceToDevice, h->st));
   CD_API_END

@@ -137,6 +137,10 @@ class Engine:
         self.h = h
         self._descs = {}
 
+    def synchronize(self):
+        """Wait for the engine's stream without spinning (cd_engine_synchronize)."""
+        check(self.lib.cd_engine_synchronize(self.h))
+
     def close(self):
         if getattr(self, "h", None):
             torch.cuda.synchronize(self.device)

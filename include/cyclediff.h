@@ -92,6 +92,11 @@ int cd_act_format(void);
 int cd_engine_create(void* hip_stream, size_t workspace_bytes, cd_handle* out);
 int cd_engine_destroy(cd_handle h);
 int cd_engine_workspace_high_water(cd_handle h, size_t* bytes);
+/* wait for everything queued on the engine's stream, SLEEPING (blocking-sync event) instead of spinning: what a rank
+ * calls where the reference's Trainer would call torch.cuda.synchronize() (trainer/trainer.py:1055-1062 times
+ * evaluate() around it). The sampler entry points also pace themselves: the host never runs more than two sampler
+ * steps ahead of the GPU (CYCLEDIFF_HOST_PACING=0 turns that off). */
+int cd_engine_synchronize(cd_handle h);
 /* per-launch timing of the implicit-GEMM kernel family with HIP events on the engine's stream
  * (bench.py roofline leg): enable, run, then collect launches / summed ms / summed 2*M*N*K flops */
 int cd_prof_enable(cd_handle h, int on);

@@ -15,7 +15,10 @@ import os
 import sys
 import types
 
-REF = os.environ.get("CYCLEDIFF_REFERENCE", "/root/reference")
+_HERE = os.path.dirname(os.path.abspath(__file__))
+# the reference tree where it lies; on the GPU box (no /root/reference) the subset staged by oracle/stage_reference.py
+REF = os.environ.get("CYCLEDIFF_REFERENCE") or (
+    "/root/reference" if os.path.isdir("/root/reference") else os.path.join(_HERE, "_ref"))
 
 
 def available():
