@@ -72,6 +72,8 @@ SIGNATURES = {
     "cd_op_pack_conv_weight": [_VP, _VP, _I, _I, _I, _I, _I, C.POINTER(_VP), C.POINTER(_I), C.POINTER(_I)],
     "cd_op_free": [_VP, _VP],
     "cd_op_conv2d": [_VP, _VP, _I, _VP, _I, _I, _I, _I, _VP, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP],
+    "cd_op_conv2d_16": [_VP, _VP, _I, _VP, _I, _I, _I, _I, _VP, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP,
+                        _VP],
     "cd_op_groupnorm": [_VP, _VP, _I, _I, _I, _I, _I, _F, _VP, _VP, _VP, _I, _VP],
     "cd_op_layernorm": [_VP, _VP, _I, _I, _VP, _VP, _F, _VP],
     "cd_op_attention": [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _F, _I, _VP],

@@ -588,11 +588,10 @@ int cd_op_pack_conv_weight(cd_handle h, const float* w_host, int N, int Cin, int
 
 int cd_op_free(cd_handle, void*) { return 0; }  // op weights live until the engine is destroyed
 
-int cd_op_conv2d(cd_handle h, const float* x0, int C0, const float* x1, int C1, int B, int H, int W,
-                 const void* packed_w, int N, int KH, int KW, int stride, int pad, int asym_pad, int up,
-                 const float* bias, const float* rowvec, const float* resid, int act, int tile, float* y) {
-  CD_API_BEGIN
-  enter_engine(h);
+static void op_conv2d(cd_handle h, const float* x0, int C0, const float* x1, int C1, int B, int H, int W,
+                      const void* packed_w, int N, int KH, int KW, int stride, int pad, int asym_pad, int up,
+                      const float* bias, const float* rowvec, const float* resid, int act, int tile, bool out16,
+                      float* y, float* stats) {
   CD_CHECK(h && x0 && packed_w && y, "bad argument");
   ArenaScope arena_scope(h->arena);
   Ctx c = h->ctx();
@@ -608,7 +607,8 @@ int cd_op_conv2d(cd_handle h, const float* x0, int C0, const float* x1, int C1, 
     launch_nchw_to_nhwc(h->st, x1, a1.p, B, C1, H * W, C1, 1.f, 0.f, 0);
   }
   ConvOpts o; o.stride = stride; o.pad = pad; o.asym = asym_pad != 0; o.up = up != 0; o.act = act; o.tile = tile;
-  o.out_f32 = true;
+  o.out_f32 = !out16;
+  o.want_stats = stats != nullptr;
   const int Hin = up ? 2 * H : H, Win = up ? 2 * W : W;
   const int Ho = asym_pad ? (Hin + 1 - KH) / stride + 1 : (Hin + 2 * pad - KH) / stride + 1;
   const int Wo = asym_pad ? (Win + 1 - KW) / stride + 1 : (Win + 2 * pad - KW) / stride + 1;
@@ -621,7 +621,32 @@ int cd_op_conv2d(cd_handle h, const float* x0, int C0, const float* x1, int C1, 
     o.resid = &r;
   }
   Act out = conv_fwd(c, w, a0, x1 ? &a1 : nullptr, o);
-  launch_nhwc_to_nchw(h->st, out.p, 1, out.ld, y, B, Nout, Ho * Wo, 1.f, 0.f);
+  launch_nhwc_to_nchw(h->st, out.p, out16 ? 0 : 1, out.ld, y, B, Nout, Ho * Wo, 1.f, 0.f);
+  if (stats) {
+    CD_CHECK(out.stats, "this convolution produces no GroupNorm statistics (GEGLU, or rows %% 32 != 0)");
+    HIP_CHECK(hipMemcpyAsync(stats, out.stats, (size_t)(out.rows() / 32) * 2 * Nout * sizeof(float),
+                             hipMemcpyDeviceToDevice, h->st));
+  }
+}
+
+int cd_op_conv2d(cd_handle h, const float* x0, int C0, const float* x1, int C1, int B, int H, int W,
+                 const void* packed_w, int N, int KH, int KW, int stride, int pad, int asym_pad, int up,
+                 const float* bias, const float* rowvec, const float* resid, int act, int tile, float* y) {
+  CD_API_BEGIN
+  enter_engine(h);
+  op_conv2d(h, x0, C0, x1, C1, B, H, W, packed_w, N, KH, KW, stride, pad, asym_pad, up, bias, rowvec, resid, act, tile,
+            false, y, nullptr);
+  CD_API_END
+}
+
+int cd_op_conv2d_16(cd_handle h, const float* x0, int C0, const float* x1, int C1, int B, int H, int W,
+                    const void* packed_w, int N, int KH, int KW, int stride, int pad, int asym_pad, int up,
+                    const float* bias, const float* rowvec, const float* resid, int act, int tile, float* y,
+                    float* stats) {
+  CD_API_BEGIN
+  enter_engine(h);
+  op_conv2d(h, x0, C0, x1, C1, B, H, W, packed_w, N, KH, KW, stride, pad, asym_pad, up, bias, rowvec, resid, act, tile,
+            true, y, stats);
   CD_API_END
 }
 
@@ -813,6 +838,13 @@ extern "C" int cd_op_bench_conv(cd_handle h, int B, int H, int W, int C0, int C1
   HIP_CHECK(hipMemsetAsync(w.b, 0, (size_t)w.Npad * 4, h->st));
   hipLaunchKernelGGL(k_fill_hash16, dim3(1024), dim3(256), 0, h->st, w.w, (int64_t)wn, 17u,
                      1.0f / sqrtf((float)w.Ktot()));
+  if (k == 1 && w.Cpad == 320) {
+    w.wfrag = (bf16_t*)h->arena.alloc(wn * 2);
+    launch_pack_wfrag(h->st, w.w, w.Ktot(), w.wfrag, w.Npad);
+  }
+  const bool inplace_resid = (act & 0x100) != 0, want_stats = (act & 0x200) != 0;
+  act &= 0xff;
+  w.geglu = (act == ACT_GEGLU);
   Act a0 = alloc_act(c, B, H, W, C1 ? C0 : round_up(C0, 32));
   hipLaunchKernelGGL(k_fill_hash16, dim3(1024), dim3(256), 0, h->st, a0.p, (int64_t)a0.rows() * a0.C, 3u, 1.0f);
   Act a1;
@@ -821,6 +853,15 @@ extern "C" int cd_op_bench_conv(cd_handle h, int B, int H, int W, int C0, int C1
     hipLaunchKernelGGL(k_fill_hash16, dim3(1024), dim3(256), 0, h->st, a1.p, (int64_t)a1.rows() * a1.C, 5u, 1.0f);
   }
   ConvOpts o; o.stride = stride; o.pad = k / 2; o.up = up != 0; o.act = (act == ACT_GEGLU) ? ACT_NONE : act; o.tile = tile;
+  Act ro;
+  if (inplace_resid || want_stats) {  // the in-place residual update of the to_out / proj_out projections
+    const int ho = up ? 2 * H : (H + 2 * o.pad - k) / stride + 1;
+    ro = alloc_act(c, B, ho, ho, N, /*with_stats=*/true);
+    hipLaunchKernelGGL(k_fill_hash16, dim3(1024), dim3(256), 0, h->st, ro.p, (int64_t)ro.rows() * ro.C, 7u, 0.01f);
+    o.out = ro.p; o.out_ld = ro.ld;
+    if (inplace_resid) o.resid = &ro;
+    if (want_stats) o.out_stats = ro.stats_buf;
+  }
   const size_t mk2 = h->arena.mark();
   conv_fwd(c, w, a0, C1 ? &a1 : nullptr, o);  // warm-up
   hipEvent_t e0, e1;

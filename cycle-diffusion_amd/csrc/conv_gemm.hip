@@ -794,6 +794,23 @@ int tuned_config(hipStream_t st, const ConvGemmParams& p, bool k64) {
     ms = fminf(ms, fminf(timed(reps), timed(reps)));
     if (ms < best_ms) { best_ms = ms; best = c.id | (split << 8) | ((k64 && !use64) ? (1 << 16) : 0); }
   }
+  if (lin_stream_supports(q)) {  // the streaming schedule for the 320-channel linears (lin_stream.hip): same bits
+    auto timed = [&](int reps) {
+      HIP_CHECK(hipEventRecord(e0, st));
+      for (int r = 0; r < reps; ++r) launch_lin_stream(st, q);
+      HIP_CHECK(hipEventRecord(e1, st));
+      HIP_CHECK(hipEventSynchronize(e1));
+      float t = 0;
+      HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+      return t / reps;
+    };
+    q.splitk = 0;
+    launch_lin_stream(st, q);
+    float ms = timed(2);
+    const int reps = (int)fminf(24.f, fmaxf(2.f, 0.4f / fmaxf(ms, 1e-3f)));
+    ms = fminf(ms, fminf(timed(reps), timed(reps)));
+    if (ms < best_ms) { best_ms = ms; best = kLinStreamTile; }
+  }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   tab[key] = best;
   tune_cache_append(key, best);
@@ -819,8 +836,14 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   if ((id >> 8) > 1) pk.splitk = id >> 8;  // from the tuner, or packed into an explicit `tile` (tests, sweeps)
   id &= 0xff;
   if (pk.splitk > 1 && !pk.sk_scratch) { pk.sk_scratch = g_conv_splitk.scratch; pk.sk_flags = g_conv_splitk.flags; }
+  static const CfgInfo kLinStreamCfg = {kLinStreamTile, 256, 64, 64, "lin_stream 256 x N, K = 320"};
   const CfgInfo* ci = nullptr;
-  for (int i = 0; i < kNumCfgs; ++i) if (kCfgs[i].id == id) ci = &kCfgs[i];
+  if (id == kLinStreamTile) {
+    // a table entry made where the shape qualified (e.g. with 16-bit output) may meet a call that does not: fall back
+    if (lin_stream_supports(pk)) ci = &kLinStreamCfg;
+    else { CD_CHECK(!p.tile, "conv_gemm: lin_stream does not support this problem"); id = pick_config(p); }
+  }
+  for (int i = 0; i < kNumCfgs && !ci; ++i) if (kCfgs[i].id == id) ci = &kCfgs[i];
   CD_CHECK(ci, "conv_gemm: unknown tile configuration %d", id);
   if (p.act == ACT_GEGLU && (ci->TN % 64) != 0) { id = 2; ci = &kCfgs[1]; }
   if (cfg_needs_bk64(id)) CD_CHECK(k64, "conv_gemm: tile configuration %d needs channel counts that are multiples of 64", id);
@@ -840,7 +863,8 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
     hipEvent_t e; hipStream_t s;
     ~Closer() { if (e) (void)hipEventRecord(e, s); }
   } closer{e1, st};
-  if (k64) dispatch<64>(st, pk, id);
+  if (id == kLinStreamTile) launch_lin_stream(st, pk);
+  else if (k64) dispatch<64>(st, pk, id);
   else dispatch<32>(st, pk, id);
 }
 

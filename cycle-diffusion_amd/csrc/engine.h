@@ -47,6 +47,7 @@ struct Act {  // NHWC activation view: 16-bit elements, or fp32 when f32 is set 
 // ------------------------------------------------------------------ parameters
 struct ConvW {  // packed conv / linear weight: 16-bit (or fp32 when f32) [Npad][KH*KW*Cpad], fp32 bias[N]
   bf16_t* w = nullptr;
+  bf16_t* wfrag = nullptr;  // the same rows in MFMA-fragment-major order for lin_stream.hip (1x1, 320 input channels)
   bool f32 = false;
   float* b = nullptr;
   int N = 0, Cin = 0, Cpad = 0, KH = 1, KW = 1, Npad = 0;

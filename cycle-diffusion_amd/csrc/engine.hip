@@ -42,6 +42,8 @@ ConvW* ParamStore::new_conv(int N, int Cin, int KH, int KW, bool bias, bool gegl
   c->Npad = round_up(N, 128);
   c->f32 = f32;
   c->w = (bf16_t*)dmalloc((size_t)c->Npad * c->Ktot() * (f32 ? sizeof(float) : sizeof(bf16_t)));
+  if (!f32 && KH == 1 && KW == 1 && c->Cpad == 320)  // the streaming linear kernel reads fragment-major weights
+    c->wfrag = (bf16_t*)dmalloc((size_t)c->Npad * c->Cpad * sizeof(bf16_t));
   if (bias) c->b = (float*)dmalloc((size_t)c->Npad * sizeof(float));
   return c;
 }
@@ -184,6 +186,7 @@ void ParamStore::load(hipStream_t st, const std::string& name, const float* host
       else
         hipLaunchKernelGGL(k_pack_rows<bf16_t>, dim3(grid), dim3(256), 0, st, staging_, c->w, t.rows, c->Cin, c->KH,
                            c->KW, c->Cpad, t.dst_row0, t.src_base, t.grp, t.grp_stride, t.geglu ? 1 : 0, c->N, t.scale);
+      if (c->wfrag) launch_pack_wfrag(st, c->w, c->Ktot(), c->wfrag, c->Npad);  // whole matrix: rows may come in parts
     } else {
       // small: map on the host
       const int K = (t.kind == PackTarget::MATRIX_F32) ? t.K : 1;
@@ -246,7 +249,7 @@ Act conv_fwd(Ctx& c, const ConvW& w, const Act& x, const Act* x2, const ConvOpts
     p.Wout = (p.Win + 2 * o.pad - w.KW) / o.stride + 1;
   }
   p.M = x.B * p.Hout * p.Wout;
-  p.wgt = w.w; p.Ktot = w.Ktot(); p.N = w.N;
+  p.wgt = w.w; p.wgt_frag = w.wfrag; p.Ktot = w.Ktot(); p.N = w.N;
   p.alpha = o.alpha; p.bias = w.b;
   p.rowvec = o.rowvec; p.rowvec_ld = o.rowvec_ld; p.rows_per_vec = o.rows_per_vec;
   p.act = w.geglu ? ACT_GEGLU : o.act;

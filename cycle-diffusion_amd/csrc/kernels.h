@@ -58,6 +58,7 @@ struct ConvGemmParams {
   int M = 0;                 // B*Hout*Wout
   // B operand: weights [Npad][Ktot] bf16, k = (r*KW+s)*(C0+C1) + c
   const bf16_t* wgt = nullptr;
+  const bf16_t* wgt_frag = nullptr;  // the same weights in MFMA-fragment-major order (lin_stream.hip), or null
   int Ktot = 0, N = 0;
   int ldw = 0;               // weight row stride in elements (0 = Ktot)
   // batched GEMM (grid.z): element strides
@@ -96,6 +97,25 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p);
 const char* conv_gemm_last_config();
 int conv_gemm_num_configs();
 const char* conv_gemm_config_name(int id);
+
+// ---------------------------------------------------------------- streaming linear layer, K = 320 (lin_stream.hip)
+// out[M][N] = epi(A[M][320] . W[N][320]^T): A strips resident in registers and prefetched a strip ahead, W streamed
+// through LDS in fragment-major order, persistent workgroups. Part of the implicit-GEMM family: launch_conv_gemm
+// dispatches to it (tile id kLinStreamTile) for the shapes lin_stream_supports() accepts.
+struct LinStreamParams {
+  const bf16_t* a = nullptr; int lda = 0;
+  const bf16_t* wfrag = nullptr;
+  const float* bias = nullptr;
+  const bf16_t* resid = nullptr; int ldr = 0;
+  bf16_t* out = nullptr; int ldo = 0;
+  float* stats = nullptr;
+  int M = 0, N = 0;
+};
+constexpr int kLinStreamTile = 30;
+bool lin_stream_supports(const ConvGemmParams& p);
+void launch_lin_stream(hipStream_t st, const ConvGemmParams& p);
+// standard packed rows [N][ldw] (K = 320 used) -> fragment-major blocks [N / 32][20][64][8]
+void launch_pack_wfrag(hipStream_t st, const bf16_t* w, int ldw, bf16_t* out, int N);
 
 // Optional per-launch timing of the dominant kernel family with HIP events recorded on the launch
 // stream (bench.py's roofline leg). flops = 2*M*N*K per launch (algorithmic, padding excluded except

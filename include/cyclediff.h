@@ -177,6 +177,13 @@ int cd_op_free(cd_handle h, void* dev);
 int cd_op_conv2d(cd_handle h, const float* x0, int C0, const float* x1, int C1, int B, int H, int W,
                  const void* packed_w, int N, int KH, int KW, int stride, int pad, int asym_pad, int up,
                  const float* bias, const float* rowvec, const float* resid, int act, int tile, float* y);
+/* the same convolution with the engine's 16-bit output (the product path's format; y still arrives as fp32 NCHW) and,
+ * if `stats` is given, the fused GroupNorm statistics of the output: fp32 [B*Ho*Wo / 32][2][N] = per-channel sum |
+ * sum of squares over each block of 32 rows. tile = 30 selects the streaming K = 320 linear kernel (lin_stream.hip). */
+int cd_op_conv2d_16(cd_handle h, const float* x0, int C0, const float* x1, int C1, int B, int H, int W,
+                    const void* packed_w, int N, int KH, int KW, int stride, int pad, int asym_pad, int up,
+                    const float* bias, const float* rowvec, const float* resid, int act, int tile, float* y,
+                    float* stats);
 int cd_op_groupnorm(cd_handle h, const float* x, int B, int C, int H, int W, int G, float eps,
                     const float* gamma, const float* beta, const float* film, int silu, float* y);
 int cd_op_layernorm(cd_handle h, const float* x, int rows, int C, const float* gamma, const float* beta,
@@ -191,7 +198,8 @@ int cd_op_timestep_embedding(cd_handle h, const float* t, int B, int dim, int mo
 int cd_op_sched_step(cd_handle h, int mode, int sched_kind, const cd_step_coef* coef_host, const float* x0,
                      float* xt, const float* eps_hat, int cfg, float guidance, const float* noise,
                      const float* eps_in, int is_last, int B, int C, int HW, float* z_slot);
-/* micro-benchmark of one conv / GEMM shape on synthetic data (scripts/bench_gemm.py): average ms per launch */
+/* micro-benchmark of one conv / GEMM shape on synthetic data (scripts/bench_gemm.py): average ms per launch.
+ * act: low byte = activation; | 0x100 = in-place residual update of the output; | 0x200 = fused GroupNorm statistics */
 int cd_op_bench_conv(cd_handle h, int B, int H, int W, int C0, int C1, int N, int k, int stride, int up,
                      int act, int tile, int iters, float* ms_out);
 /* raw MFMA / LDS layout probe used by tests/test_gpu_ops.py */

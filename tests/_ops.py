@@ -75,6 +75,25 @@ def conv2d(eng, x0, w, x1=None, stride=1, pad=1, asym=False, up=False, bias=None
     return y.cpu()
 
 
+def conv2d16(eng, x0, w, stride=1, pad=1, bias=None, resid=None, act=0, tile=0, geglu=False, want_stats=False):
+    """cd_op_conv2d_16: the convolution with the engine's 16-bit output (+ the fused GroupNorm statistics)"""
+    handle, (N, Cin, KH, KW) = pack_conv(eng, w, geglu)
+    B, C0, H, W = x0.shape
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    Nout = N // 2 if geglu else N
+    y = torch.empty((B, Nout, Ho, Wo), device="cuda", dtype=torch.float32)
+    st = torch.zeros((B * Ho * Wo // 32, 2, Nout), device="cuda", dtype=torch.float32) if want_stats else None
+    b = None
+    if bias is not None:
+        b = dev(geglu_pack_vec(bias) if geglu else bias)
+    xs0 = dev(x0)
+    rs = dev(resid) if resid is not None else None
+    check(eng.lib.cd_op_conv2d_16(eng.h, ptr(xs0), C0, None, 0, B, H, W, handle, N, KH, KW, stride, pad, 0, 0, ptr(b),
+                                  None, ptr(rs), act, tile, ptr(y), ptr(st)))
+    torch.cuda.synchronize()
+    return (y.cpu(), st.cpu()) if want_stats else y.cpu()
+
+
 def groupnorm(eng, x, gamma, beta, eps, silu=False, film=None):
     B, Cc, H, W = x.shape
     y = torch.empty_like(x, device="cuda")

@@ -167,6 +167,59 @@ def test_conv_geglu(engine, report):
         _check(report, "conv2d/geglu_t%d" % tile, got, ref, rel=5e-3, mean=3e-3)
 
 
+# ---- the streaming K = 320 linear kernel (csrc/lin_stream.hip, tile id 30): the 1x1 / nn.Linear layers of the
+# 320-channel level (attention.py:37-44,171-200,211-215; proj_in / proj_out). Every case is checked against torch fp32
+# on 16-bit-rounded operands AND bit for bit against a conv_gemm.hip tile on the same operands (same k-ascending
+# reduction, same epilogue arithmetic: the autotuner may pick either without changing a result).
+LIN_STREAM_CASES = [
+    # name, B, H, W, N, bias, resid, geglu, stats, conv_gemm tile to compare with
+    ("n320_bias", 1, 32, 32, 320, True, False, False, False, 2),
+    ("n320_resid_ragged_strip", 3, 16, 24, 320, True, True, False, False, 20),
+    ("n640_qk_nobias", 1, 32, 32, 640, False, False, False, False, 1),
+    ("n960_qkv", 2, 16, 16, 960, False, False, False, False, 2),
+    ("n2560_geglu", 1, 32, 32, 2560, True, False, True, False, 22),
+    ("n320_resid_stats", 2, 32, 32, 320, True, True, False, True, 20),
+    ("n320_stats_only", 1, 32, 16, 320, True, False, False, True, 2),
+    # more strips than CUs: workgroups 0-15 take a second strip (A prefetched during the first, register hand-over)
+    ("n320_resid_272_strips", 17, 64, 64, 320, True, True, False, False, 20),
+    ("n2560_geglu_272_strips", 17, 64, 64, 2560, True, False, True, False, 22),
+    ("n640_600_strips", 75, 32, 64, 640, False, False, False, False, 20),
+]
+
+
+@pytest.mark.parametrize("case", LIN_STREAM_CASES, ids=[c[0] for c in LIN_STREAM_CASES])
+def test_lin_stream(engine, report, case):
+    name, B, H, W, N, has_bias, has_res, geglu, stats, ref_tile = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % (2 ** 31))
+    K = 320
+    x = r16(torch.randn(B, K, H, W, generator=g))
+    w = r16(torch.randn(N, K, 1, 1, generator=g) / math.sqrt(K))
+    bias = torch.randn(N, generator=g) * 0.5 if has_bias else None
+    Nout = N // 2 if geglu else N
+    res = r16(torch.randn(B, Nout, H, W, generator=g)) if has_res else None
+    kw = dict(pad=0, bias=bias, resid=res, geglu=geglu, want_stats=stats)
+    got = _ops.conv2d16(engine, x, w, tile=30, **kw)
+    alt = _ops.conv2d16(engine, x, w, tile=ref_tile, **kw)
+    if stats:
+        (got, st), (alt, st_alt) = got, alt
+    assert torch.equal(got, alt), (got - alt).abs().max().item()
+    big = B * H * W > 20000
+    if not big or not geglu:  # the large GEGLU case is pinned by the bit comparison alone (115 GFLOP on the host)
+        ref = F.conv2d(x, w, bias)
+        if geglu:
+            val, gate = ref.chunk(2, dim=1)
+            ref = val * F.gelu(gate)
+        if res is not None:
+            ref = ref + res
+        _check(report, "lin_stream/" + name, got, ref, rel=5e-3, mean=2e-3)
+        if stats:
+            rows = ref.permute(0, 2, 3, 1).reshape(-1, 32, Nout)  # 32-row blocks of the [M][N] matrix
+            want = torch.stack([rows.sum(1), (rows * rows).sum(1)], 1)
+            scale = want.abs().max().item()
+            assert (st - want).abs().max().item() < 2e-3 * scale, (st - want).abs().max().item() / scale
+            assert (st_alt - want).abs().max().item() < 2e-3 * scale
+
+
 GN_CASES = [("c320", 2, 320, 16, 16, 1e-5, True, False), ("c64", 2, 64, 8, 8, 1e-6, False, False),
             ("c2560", 1, 2560, 8, 8, 1e-5, True, False), ("c128_film", 2, 128, 16, 16, 1e-5, True, True),
             ("c32", 1, 32, 32, 32, 1e-6, True, False), ("c1920", 1, 1920, 16, 16, 1e-5, True, False),
