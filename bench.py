@@ -77,7 +77,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(eng, un, vn, seed=0):
+def cpu_baseline(eng, un, vn, seed=0, quick=False):
     """The CPU oracle (torch fp32 restatement of the reference path, oracle/) timed on this box's host cores on a
     bounded sample of the C2 workload at batch 1: (i) the SD U-Net forward at batch 1 and at batch 2
     (the CFG pair), best of 3 each, one VAE encode and one decode at 512x512, extrapolated linearly to 99 + 99 steps;
@@ -99,18 +99,24 @@ def cpu_baseline(eng, un, vn, seed=0):
         x = torch.randn(2, 4, 64, 64, generator=g)
         ctx = torch.randn(2, 77, 768, generator=g)
         t = torch.tensor([501, 501])
-        def best_of(fn, n=3):
+        def best_of(fn, n=1 if quick else 3):
             ts = []
             for _ in range(n):
                 t0 = time.time(); fn(); ts.append(time.time() - t0)
             return min(ts), ts
 
-        nets.openai_unet(usd, ucfg, x[:1], t[:1], ctx[:1])  # warm-up (thread pool, allocator)
+        if not quick:
+            nets.openai_unet(usd, ucfg, x[:1], t[:1], ctx[:1])  # warm-up (thread pool, allocator)
         t_u1, l1 = best_of(lambda: nets.openai_unet(usd, ucfg, x[:1], t[:1], ctx[:1]))
         t_u2, l2 = best_of(lambda: nets.openai_unet(usd, ucfg, x, t, ctx))
         img = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
         t0 = time.time(); mom = nets.vae_encode_moments(vsd, vcfg, img); t_e = time.time() - t0
         t0 = time.time(); nets.vae_decode(vsd, vcfg, mom[:, :4]); t_d = time.time() - t0
+        if quick:
+            per_img = t_e + N_STEPS * t_u1 + N_STEPS * t_u2 + t_d
+            return {"value": 1.0 / per_img, "unit": "images/s", "cores": cores, "kind": "port",
+                    "sample": "oracle port: one U-Net forward @B=1 %.2fs + @B=2 %.2fs + VAE enc %.2fs + dec %.2fs, "
+                              "extrapolated to 99 + 99 steps (%.0f s/image)" % (t_u1, t_u2, t_e, t_d, per_img)}
         # (ii) a real short loop: 5 encode steps + 5 CFG-3 decode steps of the sampler restatement
         S = 5
         unet = lambda xx, tt, cc: nets.openai_unet(usd, ucfg, xx, tt, cc)
@@ -131,6 +137,60 @@ def cpu_baseline(eng, un, vn, seed=0):
                       "s/image); cross-check: real 5-step encode %.2fs + 5-step CFG decode %.2fs loop -> %.0f s/image"
                       % (t_u1, " ".join("%.2f" % v for v in l1), t_u2, " ".join("%.2f" % v for v in l2), t_e, t_d,
                          per_img, t_enc5, t_dec5, per_img_loop)}
+
+
+def cpu_baseline_reference():
+    """The REFERENCE's own modules (UNetModel / Encoder / Decoder / DDIMSampler.ddpm_ddim_encoding / sample_with_eps,
+    BASELINE.md §3) timed on this box's host cores, fp32, batch 1, on a bounded sample of the C2 workload: VAE encode at
+    512 x 512, the LAST 3 of the 99 DPM-Encoder steps (skip_steps = 96 on the real 99-step schedule; every step costs
+    the same), 3 decode steps with classifier-free guidance 3 (batch 2 forwards), VAE decode; extrapolated linearly to
+    99 + 99 steps. The modules come from /root/reference where it is mounted, else from oracle/_ref/ (staged by
+    oracle/stage_reference.py at build time, git-ignored, travels with the built library). None if neither exists."""
+    from oracle import ref_import
+    if not ref_import.available():
+        return None
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    with ref_import.session():
+        from oracle.gen_golden import RefVAE
+        from oracle.gen_golden_full import FULL_VAE, SD_UNET
+        from ldm.modules.diffusionmodules.openaimodel import UNetModel
+        Sampler = ref_import.ddim_sampler_cls()
+        g = torch.Generator().manual_seed(3)
+        with torch.no_grad():
+            with torch.device("meta"):
+                u = UNetModel(**SD_UNET)
+                v = RefVAE(FULL_VAE)
+            for m in (u, v):  # random weights without the modules' slow default initialisers
+                m.to_empty(device="cpu")
+                for prm in m.parameters():
+                    prm.normal_(0.0, 0.02, generator=g)
+                m.eval()
+            shim = ref_import.LatentShim(u)
+            img = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
+            c_src, c_tgt, uc = (torch.randn(1, 77, 768, generator=g) for _ in range(3))
+            t0 = time.time(); x0 = v.moments(img)[:, :4] * 0.18215; t_e = time.time() - t0
+            S, skip = 99, 96
+            with ref_import.quiet():
+                t0 = time.time()
+                z = Sampler(shim).ddpm_ddim_encoding(S, batch_size=1, shape=(4, 64, 64), conditioning=c_src, eta=0.1,
+                                                     white_box_steps=S + 1, skip_steps=skip, verbose=False, x0=x0,
+                                                     unconditional_guidance_scale=1, unconditional_conditioning=uc)
+                t_enc = time.time() - t0
+                z = torch.stack(z, dim=1)
+                n_steps = z.shape[1] - 1
+                t0 = time.time()
+                x, _ = Sampler(shim).sample_with_eps(S, z[:, 1:], conditioning=c_tgt, batch_size=1, shape=(4, 64, 64),
+                                                     eta=0.1, verbose=False, x_T=z[:, 0], skip_steps=skip,
+                                                     unconditional_guidance_scale=3.0, unconditional_conditioning=uc)
+                t_dec = time.time() - t0
+            t0 = time.time(); v.decode(x / 0.18215); t_d = time.time() - t0
+    per_img = t_e + S * t_enc / n_steps + S * t_dec / n_steps + t_d
+    return {"value": 1.0 / per_img, "unit": "images/s", "cores": cores, "kind": "reference",
+            "sample": "the reference's own UNetModel / Encoder / Decoder / DDIMSampler (CPU fp32, batch 1, %s): VAE encode "
+                      "%.2fs + %d DPM-Encoder steps %.2fs + %d CFG-3 decode steps %.2fs + VAE decode %.2fs at 512x512, "
+                      "extrapolated linearly to 99 + 99 steps (%.0f s/image)"
+                      % (ref_import.REF, t_e, n_steps, t_enc, n_steps, t_dec, t_d, per_img)}
 
 
 def pmc_traffic_per_launch():
@@ -356,7 +416,13 @@ def main():
                                    "ms_per_step": 1e3 * single_dt / a.single_steps, "images_in_flight_per_gpu": B,
                                    "whole_path_frac": sv * wl["flop_per_image"] / 1e12 / (world * peak)}
         if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
-            res["cpu_baseline"] = cpu_baseline(eng, wrapper.unet, wrapper.vae)
+            ref = cpu_baseline_reference()
+            if ref is not None:  # the reference itself; the oracle port's forward-extrapolated figure beside it
+                port = cpu_baseline(eng, wrapper.unet, wrapper.vae, quick=True)
+                ref["port_value"], ref["port_sample"] = port["value"], port["sample"]
+                res["cpu_baseline"] = ref
+            else:
+                res["cpu_baseline"] = cpu_baseline(eng, wrapper.unet, wrapper.vae)
         print(json.dumps(res), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -133,6 +133,7 @@ __device__ inline float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7
 // 0.5 x q for x < 0 and 0.5 x (2 - q) otherwise, q = poly(t) exp(-x^2 / 2), so the negative tail does not cancel.
 // 13 VALU operations instead of ~35 for erff: the GEGLU layers are 17 % of the GEMM time and epilogue-bound.
 __device__ inline float gelu_fast(float x) {
+#pragma clang fp contract(off)  // the same bits wherever it is inlined (conv_gemm.hip and lin_stream.hip must agree)
   const float z = fabsf(x) * 0.70710678118654752440f;
   const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
   float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);

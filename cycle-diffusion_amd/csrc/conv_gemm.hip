@@ -736,7 +736,7 @@ int tuned_config(hipStream_t st, const ConvGemmParams& p, bool k64) {
   ConvTuner& tu = g_conv_tuner;
   if (!tu.enabled || !tu.scratch) return pick_config(p);
   const int nout = (p.act == ACT_GEGLU) ? p.N / 2 : p.N;
-  const size_t need = (size_t)p.M * nout * 4 * p.nbatch;
+  const size_t need = (size_t)p.M * nout * (p.out_f32 ? 4 : 2) * p.nbatch;
   if (need > tu.scratch_bytes) return pick_config(p);
   ShapeKey key = {{p.M, p.N, p.Ktot, p.KH, p.C0, p.C1, p.stride, p.up, p.act, p.nbatch, p.out_f32, p.Hout, p.Wout,
                    (p.resid ? 1 : 0) | (p.rowvec ? 2 : 0)}};

@@ -17,8 +17,9 @@
 //     at a time) as 16-byte stores with bias / residual / GEGLU / GroupNorm statistics fused, one rounding to 16 bits.
 //   * roles: waves 0-3 issue the W pieces, waves 4-7 the A pieces, so the W waits (L2 latency) never queue behind A loads
 //     (HBM latency) in a wave's in-order VMEM counter. Every wait is COUNTED: each wave keeps a running count of the
-//     VMEM operations it has issued and remembers the count after each piece; the wait for a piece is
-//     s_waitcnt vmcnt(now - then), rounded down to a multiple of 4. Residual loads go through inline asm (hipcc drains
+//     LOADS it has issued and remembers the count after each piece; the wait for a piece is s_waitcnt
+//     vmcnt(now - then), rounded down to a multiple of 4 (stores are left out of the count: they may retire out of
+//     order with respect to loads, and leaving them out makes a wait cover them as well). Residual loads go through inline asm (hipcc drains
 //     vmcnt(0) for an ordinary load beside LDS-DMA) and are issued one tile ahead.
 // Per-element reduction order is k-ascending, as in conv_gemm.hip: results are bit-identical to its tiles.
 #include <mutex>
@@ -174,8 +175,8 @@ __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
     }
   };
 
-  // ---- VMEM bookkeeping (all wave-uniform): seq = operations issued so far by this wave; a mark = seq right after
-  // the operations someone will wait for
+  // ---- VMEM bookkeeping (all wave-uniform): seq = LOADS (LDS-DMA and residual loads; never stores, see the epilogue)
+  // issued so far by this wave; a mark = seq right after the loads someone will wait for
   int seq = 0;
   int wm0 = 0, wm1 = 0;          // W pieces of the current and the next iteration
   int am0 = 0, am1 = 0, a_fly = 0;  // A pieces in flight (front, back)
@@ -383,7 +384,10 @@ __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
           }
         }
       }
-      if (rows_ok) seq += GEGLU ? 2 : 4;  // the statistics stores are not counted (an under-count only over-waits)
+      // Stores are NOT counted in `seq`: gfx9-family hardware may retire stores out of order with respect to loads
+      // (only loads return in order among themselves), so a count that allowed "the younger stores" to be outstanding
+      // could be satisfied by early stores while the awaited load is still in flight - seen on hardware as stale A
+      // pieces once a workgroup runs a second strip. Counting LOADS only makes every wait also cover older stores.
       // residual rows of the next tile (of the next strip after the last tile): a whole tile of lead
       if (RESID) {  // ONE issue site inside the loop: every asm statement defines its own set of result registers
         const bool last = t + 1 == NT;
