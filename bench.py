@@ -64,6 +64,25 @@ WORKLOADS = {
 }
 
 
+def thread_cpu_seconds():
+    """user + system CPU seconds of every thread of this process, by (tid, name) - which thread burns the host cores"""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                with open("/proc/self/task/%s/stat" % tid) as fh:
+                    st = fh.read()
+                name = st[st.index("(") + 1:st.rindex(")")]
+                f = st[st.rindex(")") + 2:].split()
+                out[(int(tid), name)] = (int(f[11]) + int(f[12])) / tick
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        pass
+    return out
+
+
 def host_cores():
     """CPU cores this process may actually use: min(affinity mask, cgroup-v2 quota). (The GPU box shows
     256 logical CPUs but caps the container at 16; oversubscribing a quota throttles everything.)"""
@@ -340,11 +359,14 @@ def main():
         done += C
     sync()
     c0 = time.process_time()
+    th0 = thread_cpu_seconds()
     t0 = time.perf_counter()
     out = run_sets(sets)  # exactly --steps steps
     sync()
     dt = time.perf_counter() - t0
     host_cpu = time.process_time() - c0  # CPU seconds of this rank (all its threads) over the timed region
+    th1 = thread_cpu_seconds()
+    busiest = sorted(((th1[k] - th0.get(k, 0.0)) / dt, k[1]) for k in th1)[-3:][::-1]
     if dist.is_initialized():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -395,6 +417,7 @@ def main():
                        # CPU seconds of this rank (all threads) per wall second of the timed region: the launching thread
                        # sleeps in blocking-sync events (engine step pacing, cd_engine_synchronize)
                        "host_cpu_cores_used": host_cpu / dt,
+                       "host_busiest_threads": ["%s %.2f" % (n, c) for c, n in busiest],
                        "storage": ("fp32 activations / weights, v_mfma_f32_32x32x2_f32 (the reference's arithmetic)" if f32
                                    else "%s activations / weights, fp32 accumulate (BASELINE.json's C2 line says bf16: same "
                                         "width and MFMA rate; fp16 keeps the DPM-Encoder's 1/sigma amplification 8x smaller, "
