@@ -22,6 +22,8 @@
 //     order with respect to loads, and leaving them out makes a wait cover them as well). Residual loads go through inline asm (hipcc drains
 //     vmcnt(0) for an ordinary load beside LDS-DMA) and are issued one tile ahead.
 // Per-element reduction order is k-ascending, as in conv_gemm.hip: results are bit-identical to its tiles.
+#include <stdlib.h>
+
 #include <mutex>
 
 #include "common.h"
@@ -75,11 +77,32 @@ __device__ __forceinline__ u32x4 load16_hidden(u32x4 rsrc, unsigned voff) {
   asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r) : "v"(voff), "s"(rsrc) : "memory");
   return r;
 }
+// eight fp32 values -> the 16-bit storage format, saturating like f2bf(): one v_med3 per value and one packed convert per
+// pair (common.h's pack8 compiles to two compare / select pairs, a convert, an SDWA convert and an OR per pair: ~56
+// VALU operations per vector, a fifth of this kernel's GEGLU epilogue). Same bits as pack8 for every non-NaN input
+// (a NaN saturates here instead of passing through).
+__device__ __forceinline__ uint4 pack8_sat(const float* f) {
+#if CD_ACT_FP16
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const h2 v = {(_Float16)__builtin_amdgcn_fmed3f(f[2 * i], -65504.0f, 65504.0f),
+                  (_Float16)__builtin_amdgcn_fmed3f(f[2 * i + 1], -65504.0f, 65504.0f)};
+    w[i] = __builtin_bit_cast(uint32_t, v);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+#else
+  return pack8(f);
+#endif
+}
 __device__ __forceinline__ void touch4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
   asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
 }
 
-template <int ACT, bool RESID, bool STATS>
+// DBG (statistics variants only, selected by CYCLEDIFF_LIN_DBG for hardware bisection; 0 in the product):
+// 1 = no lgkmcnt wait after the write-back, 2 = no global statistics stores, 3 = no column-sum pass, 4 = no write-back
+template <int ACT, bool RESID, bool STATS, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr bool GEGLU = (ACT == ACT_GEGLU);
@@ -182,28 +205,47 @@ __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
   int am0 = 0, am1 = 0, a_fly = 0;  // A pieces in flight (front, back)
   int rmark = 0;                 // residual rows of the coming tile
 
-  // ---- the A stream: element e = (strip ordinal e / 10, piece e % 10) in order; ordinal 0 is consumed by the
-  // prologue (pseudo-iterations -10 .. -1), ordinal o >= 1 during strip o - 1 at iteration I - 10 cs + j cs
-  auto a_cons_iter = [&](int e) {  // global (pseudo-)iteration at which element e is copied to registers
-    const int o = e / NAP, j = e - o * NAP;
-    return o == 0 ? j - NAP : (o - 1) * I + I - NAP * cs + j * cs;
-  };
-  auto a_issue_iter = [&](int e) { return a_cons_iter(e) - (e < NAP ? 2 : 2 * cs); };
-  const int a_total = my_count * NAP;
-  int e_issue = 0, e_cons = 0;   // next element to issue / to consume
-  auto a_step_issue = [&](int gi) {  // A-issuer waves: issue the element due at pseudo-iteration gi (at most one)
-    if (e_issue < a_total && a_issue_iter(e_issue) <= gi) {
-      const int o = e_issue / NAP, j = e_issue - o * NAP;
+  // ---- the A stream: elements (strip ordinal o, piece j) in order; ordinal 0 is consumed by the prologue
+  // (pseudo-iterations -10 .. -1, issued 2 earlier), ordinal o >= 1 during strip o - 1 at iteration
+  // (o - 1) I + I - 10 cs + j cs, issued 2 cs earlier. All state advances incrementally (wave-uniform scalars: the
+  // loop body is latency-critical and SALU divisions / the branches around them were ~150 instructions per iteration)
+  int e_issue = 0, e_cons = 0;               // elements issued / consumed so far
+  int is_o = 0, is_j = 0, is_gi = -NAP - 2;  // next element to issue: strip ordinal, piece, (pseudo-)iteration
+  int is_slot = 0, is_row0 = (int)blockIdx.x * 256;
+  int cn_o = 0, cn_j = 0, cn_gi = -NAP, cn_slot = 0;  // next element to consume
+  // (updates are written with selects, not if / else pairs: the compiler sinks the two stores of such a pair into one
+  // dynamically addressed store, which sends the whole state block to scratch memory and the loop to exec masking)
+  auto a_step_issue = [&](int gi) {  // issue the element due at pseudo-iteration gi (at most one per call)
+    if (is_o < my_count && is_gi <= gi) {
       if (!w_issuer) {
-        issue_a(((int)blockIdx.x + o * G) * 256, j, e_issue % ASLOTS);
+        issue_a(is_row0, is_j, is_slot);
         seq += 4;
-        if (a_fly == 0) am0 = seq; else am1 = seq;
+        am0 = a_fly == 0 ? seq : am0;
+        am1 = a_fly == 0 ? am1 : seq;
       }
+      const bool wrap = is_j == NAP - 1;
+      const int step_in = is_o == 0 ? 1 : cs, step_wrap = is_o == 0 ? I - 12 * cs + 3 : I - 9 * cs;
       ++a_fly;
       ++e_issue;
+      is_slot = is_slot == ASLOTS - 1 ? 0 : is_slot + 1;
+      is_gi += wrap ? step_wrap : step_in;
+      is_j = wrap ? 0 : is_j + 1;
+      is_o += wrap ? 1 : 0;
+      is_row0 += wrap ? G * 256 : 0;
     }
   };
-  auto a_due = [&](int gi) { return e_cons < e_issue && a_cons_iter(e_cons) <= gi; };
+  auto a_due = [&](int gi) { return e_cons < e_issue && cn_gi <= gi; };
+  int ce_j = 0, ce_slot = 0;  // the element being consumed in this iteration
+  auto a_consume_step = [&]() {  // bookkeeping of one consumption (at most two pieces are ever in flight)
+    const bool wrap = cn_j == NAP - 1;
+    const int step_in = cn_o == 0 ? 1 : cs, step_wrap = cn_o == 0 ? I - 10 * cs + 1 : I - 9 * cs;
+    ce_j = cn_j; ce_slot = cn_slot;
+    am0 = am1; --a_fly; ++e_cons;
+    cn_slot = cn_slot == ASLOTS - 1 ? 0 : cn_slot + 1;
+    cn_gi += wrap ? step_wrap : step_in;
+    cn_j = wrap ? 0 : cn_j + 1;
+    cn_o += wrap ? 1 : 0;
+  };
 
   // ---- prologue: W pieces 0 and 1; the first strip's A through the ring into `afn`, then afn -> af
   if (w_issuer) {
@@ -216,10 +258,9 @@ __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
     const bool due = a_due(gi);
     if (due && !w_issuer) wait_vmcnt_le(seq - am0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    const int ce = e_cons;
-    if (due) { am0 = am1; --a_fly; ++e_cons; }  // at most two pieces are ever in flight
+    if (due) a_consume_step();
     a_step_issue(gi);
-    if (due) take_a(ce % NAP, ce % ASLOTS);
+    if (due) take_a(ce_j, ce_slot);
   }
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) af[ks] = afn[ks];
@@ -272,8 +313,7 @@ __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
           seq += 5;
           wm0 = wm1; wm1 = seq;
         }
-        const int ce = e_cons;
-        if (due) { am0 = am1; --a_fly; ++e_cons; }
+        if (due) a_consume_step();
         a_step_issue(gi);
         // ---- 10 k slices x 2 column blocks. Fragment reads are pinned (the scheduler would otherwise hoist as many as
         // registers allow, and this kernel has none to spare): one slice ahead, or - residual variants, which also hold
@@ -288,23 +328,27 @@ __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
             __builtin_amdgcn_sched_barrier(0);
           }
         } else {
-          bf16x8 wf[2][2];
-          wf[0][0] = *(const bf16x8*)(wp);
-          wf[0][1] = *(const bf16x8*)(wp + KSH * 1024);
+          constexpr int PFD = 2;  // slices read ahead
+          bf16x8 wf[PFD + 1][2];
+#pragma unroll
+          for (int d = 0; d < PFD; ++d) {
+            wf[d][0] = *(const bf16x8*)(wp + d * 1024);
+            wf[d][1] = *(const bf16x8*)(wp + (KSH + d) * 1024);
+          }
 #pragma unroll
           for (int ksl = 0; ksl < KSH; ++ksl) {
-            if (ksl + 1 < KSH) {
-              wf[(ksl + 1) & 1][0] = *(const bf16x8*)(wp + (ksl + 1) * 1024);
-              wf[(ksl + 1) & 1][1] = *(const bf16x8*)(wp + (KSH + ksl + 1) * 1024);
+            if (ksl + PFD < KSH) {
+              wf[(ksl + PFD) % (PFD + 1)][0] = *(const bf16x8*)(wp + (ksl + PFD) * 1024);
+              wf[(ksl + PFD) % (PFD + 1)][1] = *(const bf16x8*)(wp + (KSH + ksl + PFD) * 1024);
             }
-            acc[0] = CD_MFMA_32x32x16(wf[ksl & 1][0], af[kh * KSH + ksl], acc[0]);
-            acc[1] = CD_MFMA_32x32x16(wf[ksl & 1][1], af[kh * KSH + ksl], acc[1]);
+            acc[0] = CD_MFMA_32x32x16(wf[ksl % (PFD + 1)][0], af[kh * KSH + ksl], acc[0]);
+            acc[1] = CD_MFMA_32x32x16(wf[ksl % (PFD + 1)][1], af[kh * KSH + ksl], acc[1]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
         // the landed A piece goes to the next-strip registers after the MFMAs, when the fragment registers are free
         // (its ring slot is refilled one iteration later at the earliest, behind the next barrier's lgkmcnt(0))
-        if (due) take_a(ce % NAP, ce % ASLOTS);
+        if (due) take_a(ce_j, ce_slot);
         wslot = wslot == 2 ? 0 : wslot + 1;
         ++gi;
       }
@@ -326,6 +370,9 @@ __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
           const f32x4 v4 = {acc[nb][4 * q], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]};
           *(f32x4*)(stage + mi2 * ST_LD + 8 * q + 4 * half2) = v4;
         }
+        // the read-back lands in the registers these stores take their data from: retire them first (see the
+        // statistics write-back below for what happens otherwise)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         const int ncol0 = t * 64 + nb * 32;  // first packed column of this block
         const f32x4 b0 = *(const f32x4*)(bias_s + ncol0 + pcol), b1 = *(const f32x4*)(bias_s + ncol0 + pcol + 4);
@@ -343,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = vv[ps][e] * gelu_fast(v[e]);
               if (rows_ok) {
-                const uint4 o = pack8(v);
+                const uint4 o = pack8_sat(v);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_o, o_lane,
                                                        ((row0 + 16 * ps) * p.ldo + t * 32) * 2, 0);
               }
@@ -356,18 +403,23 @@ __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
               for (int e = 0; e < 8; ++e) v[e] += rr[e];
             }
             if (rows_ok) {
-              const uint4 o = pack8(v);
+              const uint4 o = pack8_sat(v);
               __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_o, o_lane,
                                                      ((row0 + 16 * ps) * p.ldo + ncol0) * 2, 0);
             }
-            if (STATS) {  // the final fp32 values go back to the transpose buffer for the column sums below
+            if (STATS && DBG != 4) {  // the final fp32 values go back to the transpose buffer for the column sums below
               *(f32x4*)srow = (f32x4){v[0], v[1], v[2], v[3]};
               *(f32x4*)(srow + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+              // retire these stores before their source registers are reused: on hardware, without this wait, a few
+              // waves per launch stored a wrong third dword in the NEXT pass (lanes 12-15 of every 16, this column
+              // block only) although the instruction stream is correct - the following ds_read_b128 lands in the
+              // registers the pending ds_write_b128 takes its data from
+              if (DBG != 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
           }
           __builtin_amdgcn_sched_barrier(0);  // one (column block, pass) at a time: the temporaries must not pile up
         }
-        if (STATS) {
+        if (STATS && DBG != 3) {
           // per-channel sum / sum of squares over the wave's 32 rows (= one 32-row statistics block of
           // ConvGemmParams::stats): lane l sums column l & 31 over rows 16 (l >> 5) .. +16, the halves meet by DPP
           __builtin_amdgcn_wave_barrier();
@@ -378,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
             s1 += x; s2 += x * x;
           }
           s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-          if (rows_ok && half2 == 0) {
+          if (rows_ok && half2 == 0 && DBG != 2) {
             float* sp = p.stats + (int64_t)((row0 + wave * 32) >> 5) * 2 * p.N + ncol0 + mi2;
             sp[0] = s1; sp[p.N] = s2;
           }
@@ -415,10 +467,10 @@ __global__ void k_pack_wfrag(const bf16_t* __restrict__ w, int ldw, bf16_t* __re
   }
 }
 
-template <int ACT, bool RESID, bool STATS>
+template <int ACT, bool RESID, bool STATS, int DBG = 0>
 void launch_variant(hipStream_t st, const LinStreamParams& p, int grid) {
   static std::once_flag attr_once;
-  auto kern = k_lin_stream<ACT, RESID, STATS>;
+  auto kern = k_lin_stream<ACT, RESID, STATS, DBG>;
   std::call_once(attr_once, [&]() {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   });
@@ -463,7 +515,14 @@ void launch_lin_stream(hipStream_t st, const ConvGemmParams& c) {
   if (c.act == ACT_GEGLU) launch_variant<ACT_GEGLU, false, false>(st, p, grid);
   else if (c.resid && c.stats) launch_variant<ACT_NONE, true, true>(st, p, grid);
   else if (c.resid) launch_variant<ACT_NONE, true, false>(st, p, grid);
-  else if (c.stats) launch_variant<ACT_NONE, false, true>(st, p, grid);
+  else if (c.stats) {
+    static const int dbg = [] { const char* e = getenv("CYCLEDIFF_LIN_DBG"); return e ? atoi(e) : 0; }();
+    if (dbg == 1) launch_variant<ACT_NONE, false, true, 1>(st, p, grid);
+    else if (dbg == 2) launch_variant<ACT_NONE, false, true, 2>(st, p, grid);
+    else if (dbg == 3) launch_variant<ACT_NONE, false, true, 3>(st, p, grid);
+    else if (dbg == 4) launch_variant<ACT_NONE, false, true, 4>(st, p, grid);
+    else launch_variant<ACT_NONE, false, true>(st, p, grid);
+  }
   else launch_variant<ACT_NONE, false, false>(st, p, grid);
 }
 
