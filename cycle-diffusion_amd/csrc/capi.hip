@@ -2,6 +2,7 @@
 // (DPM-Encoder / coupled decode) and single-kernel entry points used by the parity tests.
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 
@@ -23,16 +24,27 @@ struct StepPacer {
     enabled = !(e && e[0] == '0');
     for (auto& x : ev) HIP_CHECK(hipEventCreateWithFlags(&x, hipEventBlockingSync | hipEventDisableTiming));
   }
+  // hipEventSynchronize was measured to keep a core busy even on hipEventBlockingSync events (round 3, call 4: the
+  // launching thread at 1.00 core with pacing on): the wait is a query + nanosleep loop instead - with two sampler
+  // steps (tens of ms) queued, a 100 us wake-up granularity costs nothing
+  static void sleep_until_done(hipEvent_t e) {
+    for (;;) {
+      const hipError_t q = hipEventQuery(e);
+      if (q == hipSuccess) return;
+      if (q != hipErrorNotReady) HIP_CHECK(q);
+      usleep(100);
+    }
+  }
   void tick(hipStream_t st) {
     if (!enabled) return;
     HIP_CHECK(hipEventRecord(ev[n % kRing], st));
     ++n;
-    if (n > kAhead) HIP_CHECK(hipEventSynchronize(ev[(n - 1 - kAhead) % kRing]));
+    if (n > kAhead) sleep_until_done(ev[(n - 1 - kAhead) % kRing]);
   }
-  void wait_all(hipStream_t st) {  // blocking (sleeping) equivalent of hipStreamSynchronize
+  void wait_all(hipStream_t st) {  // sleeping equivalent of hipStreamSynchronize
     if (!ev[0]) { HIP_CHECK(hipStreamSynchronize(st)); return; }
     HIP_CHECK(hipEventRecord(ev[n % kRing], st));
-    HIP_CHECK(hipEventSynchronize(ev[n % kRing]));
+    sleep_until_done(ev[n % kRing]);
     ++n;
   }
   void destroy() { for (auto& x : ev) if (x) { (void)hipEventDestroy(x); x = nullptr; } }
@@ -318,7 +330,7 @@ StepCoef* upload_coef(cd_engine* h, const cd_step_coef* host, int n) {
   if (cs.host && bytes <= CoefStaging::kSlotBytes) {
     const int slot = cs.next;
     cs.next = (cs.next + 1) % CoefStaging::kSlots;
-    HIP_CHECK(hipEventSynchronize(cs.done[slot]));  // the copy that last used this slot (a never-recorded event is done)
+    StepPacer::sleep_until_done(cs.done[slot]);  // the copy that last used this slot (a never-recorded event is done)
     char* stage = cs.host + (size_t)slot * CoefStaging::kSlotBytes;
     memcpy(stage, host, bytes);
     HIP_CHECK(hipMemcpyAsync(d, stage, bytes, hipMemcpyHostToDevice, h->st));
