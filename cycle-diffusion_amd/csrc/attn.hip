@@ -44,20 +44,23 @@ constexpr int KT = 64;  // keys per tile
 // probabilities the numerator uses) instead of 32 VALU adds per tile.
 // NBUF = 2: the next tile's K / V^T are fetched into registers before the current tile's math and
 // written to the other LDS buffer after it - one barrier per tile.
-template <int DQK, int DV, int DH, int NBUF, bool VTOK, int KG>
-__global__ __launch_bounds__(256, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3) : 2) : 1) void k_attention(AttnParams p) {
+// NWV = waves per workgroup (32 queries each): 4, or 8 - a 256-query workgroup stages every K / V tile once for twice
+// the queries (half the L2 -> LDS traffic and half the staging instructions per query; same waves per SIMD)
+template <int DQK, int DV, int DH, int NBUF, bool VTOK, int KG, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3) : 2) : 1) void k_attention(AttnParams p) {
+  constexpr int NT = 64 * NWV;  // threads per workgroup
   constexpr int KLD = DQK + 8;  // elements per K row in LDS (16 B pad)
   constexpr int VLD = KT + 8;   // elements per V^T row in LDS
   constexpr int NKS = DQK / 16;
   constexpr int NDT = DV / 32;
   constexpr int CPR = DQK / 8;
-  constexpr int NKR = (KT * CPR + 255) / 256;  // staging registers (uint4) per thread
+  constexpr int NKR = (KT * CPR + NT - 1) / NT;  // staging registers (uint4) per thread
   constexpr bool ONES = DH > 0;
   // token-major V tile in LDS: [key][VS]; the row stride is 16 or 48 dwords mod 64, so the four key rows x 64 bytes
   // that the 32 lanes of a transpose-read group touch fall on 64 distinct banks
   constexpr int VS = DV <= 32 ? 32 : (DV <= 96 ? 96 : 160);
   constexpr int CPRV = ONES ? DH / 8 + 1 : DV / 8;  // 16-byte chunks staged per key row (the last one: ones column)
-  constexpr int NVR = VTOK ? (KT * CPRV + 255) / 256 : DV * 8 / 256;
+  constexpr int NVR = VTOK ? (KT * CPRV + NT - 1) / NT : (DV * 8 + NT - 1) / NT;
   constexpr int VBUF = VTOK ? KT * VS : DV * VLD;
   static_assert(!ONES || (DH < DV && (DH & 7) == 0 && ((DH >> 2) & 1) == 0), "ones row placement");
   __shared__ __attribute__((aligned(16))) bf16_t Ks[NBUF][KT * KLD];
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3) : 2)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qi = lane & 31, half = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (32 * NWV) + wave * 32;
   const int D = ONES ? DH : p.D;
 
   const bf16_t* qb = p.q + (int64_t)b * p.q_bs + h * D;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3) : 2)
   bool v_ones[NVR];
 #pragma unroll
   for (int i = 0; i < NKR; ++i) {
-    const int id = tid + i * 256;
+    const int id = tid + i * NT;
     const int row = id / CPR, ch = id % CPR;
     const bool ok = id < KT * CPR && ch * 8 < D;  // columns D .. DQK-1 of the tile are zero padding
     k_voff[i] = ok ? (unsigned)((row * p.ldk + ch * 8) * 2) : kNoLoad;
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3) : 2)
   }
 #pragma unroll
   for (int i = 0; i < NVR; ++i) {
-    const int id = tid + i * 256;
+    const int id = tid + i * NT;
     if (VTOK) {  // [key][d] like K: chunk ch of key row `row`; chunk CPRV-1 = the ones column when ONES
       const int row = id / CPRV, ch = id % CPRV;
       const bool data = id < KT * CPRV && ch * 8 < D;
@@ -127,8 +130,8 @@ __global__ __launch_bounds__(256, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3) : 2)
       v_ones[i] = ONES && ch * 8 == DH;
     } else {
       const int row = id >> 3, ch = id & 7;
-      v_voff[i] = (unsigned)((row * p.vt_tpad + ch * 8) * 2);  // rows >= vt_dpad fall outside the descriptor
-      v_loff[i] = row * VLD + (ch >> 1) * 16 + (ch & 1) * 4;
+      v_voff[i] = row < DV ? (unsigned)((row * p.vt_tpad + ch * 8) * 2) : kNoLoad;  // rows >= vt_dpad: zeros
+      v_loff[i] = row < DV ? row * VLD + (ch >> 1) * 16 + (ch & 1) * 4 : -1;
       v_ones[i] = ONES && row == DH;
     }
   }
@@ -162,8 +165,10 @@ __global__ __launch_bounds__(256, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3) : 2)
         if (v_loff[i] >= 0) *(uint4*)(&Vs[buf][v_loff[i]]) = v;
       } else {
         if (v_ones[i]) v = make_uint4(kOnePair, kOnePair, kOnePair, kOnePair);
-        *(uint2*)(&Vs[buf][v_loff[i]]) = make_uint2(v.x, v.y);
-        *(uint2*)(&Vs[buf][v_loff[i] + 8]) = make_uint2(v.z, v.w);
+        if (v_loff[i] >= 0) {
+          *(uint2*)(&Vs[buf][v_loff[i]]) = make_uint2(v.x, v.y);
+          *(uint2*)(&Vs[buf][v_loff[i] + 8]) = make_uint2(v.z, v.w);
+        }
       }
     }
   };
@@ -386,7 +391,12 @@ void launch_attention(hipStream_t st, const AttnParams& p) {
   // d = 40 (SD / LDM 320-channel level): 32-key softmax groups fit 128 VGPRs = four waves per SIMD (2 % faster than
   // 64-key groups at three: profiles/r2b_attention_v_layouts.txt); CD_ATTN_KG32=0 selects the 64-key form for A/B runs
   static const bool half_groups = [] { const char* e = getenv("CD_ATTN_KG32"); return !(e && e[0] == '0'); }();
-  if (p.D == 40 && half_groups) CD_ATTN_KG(48, 64, 40, 2, 32);
+  // 256-query workgroups (8 waves) for the long self-attention of the 64 x 64 level: CD_ATTN_W8=0 selects 128 (A/B)
+  static const bool wide_wg = [] { const char* e = getenv("CD_ATTN_W8"); return !(e && e[0] == '0'); }();
+  if (p.D == 40 && half_groups && wide_wg && p.Tq >= 1024 && p.Tk >= 1024 && p.vt) {
+    hipLaunchKernelGGL((k_attention<48, 64, 40, 2, false, 32, 8>), dim3(ceil_div(p.Tq, 256), p.H, p.B), dim3(512), 0, st,
+                       p);
+  } else if (p.D == 40 && half_groups) CD_ATTN_KG(48, 64, 40, 2, 32);
   else if (p.D == 40) CD_ATTN(48, 64, 40, 2);
   else if (p.D == 80 && half_groups) CD_ATTN_KG(80, 96, 80, 2, 32);  // 640-channel level: three waves per SIMD
   else if (p.D == 80) CD_ATTN(80, 96, 80, 2);
