@@ -618,7 +618,13 @@ static void op_conv2d(cd_handle h, const float* x0, int C0, const float* x1, int
     a1 = alloc_act(c, B, H, W, C1);
     launch_nchw_to_nhwc(h->st, x1, a1.p, B, C1, H * W, C1, 1.f, 0.f, 0);
   }
-  ConvOpts o; o.stride = stride; o.pad = pad; o.asym = asym_pad != 0; o.up = up != 0; o.act = act; o.tile = tile;
+  ConvOpts o; o.stride = stride; o.pad = pad; o.asym = asym_pad != 0; o.up = up != 0; o.tile = tile;
+  if (act & 0x400) {  // LayerNorm (no gain / bias) of the input rows inside the kernel: streaming linear kernel only
+    CD_CHECK(out16 && conv_ln_fold_available(c, w, (int64_t)B * H * W) , "LayerNorm fold needs tile 30 shapes");
+    o.ln_fold = true;
+    act &= ~0x400;
+  }
+  o.act = act;
   o.out_f32 = !out16;
   o.want_stats = stats != nullptr;
   const int Hin = up ? 2 * H : H, Win = up ? 2 * W : W;

@@ -829,6 +829,7 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   CD_CHECK((p.ld0 % 8) == 0 && (p.src1 == nullptr || (p.ld1 % 8) == 0), "conv_gemm: ld must be a multiple of 8");
   if (p.act == ACT_GEGLU) CD_CHECK(p.N % 64 == 0, "GEGLU needs packed N %% 64 == 0");
   bool k64 = (p.C0 % 64 == 0) && (p.C1 % 64 == 0);
+  if (p.ln_fold) CD_CHECK(p.tile == kLinStreamTile, "conv_gemm: a LayerNorm-folded layer runs on lin_stream only");
   int id = p.tile ? p.tile : tuned_config(st, p, k64);
   if (id & (1 << 16)) k64 = false;  // tuner (or an explicit tile | 1<<16) asks for the BK=32 variant
   ConvGemmParams pk = p;

@@ -81,6 +81,7 @@ class ParamStore {
  public:
   ~ParamStore();
   bool f32 = false;  // matrices are packed as fp32 (set by the network before it declares anything)
+  int version = 0;   // bumped by every load(): derived weights (LayerNorm folds) are rebuilt when it moves
   // allocate packed storage
   ConvW* new_conv(int N, int Cin, int KH, int KW, bool bias, bool geglu = false);
   float* new_vec(int n, float init = 0.f);
@@ -137,6 +138,10 @@ struct ConvOpts {
   bool out_f32 = false;
   void* out = nullptr;  // optional preallocated output
   int out_ld = 0;
+  // LayerNorm the input rows inside the kernel (statistics only; the weights carry gain and bias): the streaming
+  // K = 320 linear kernel only - the caller checks conv_ln_fold_available() first
+  bool ln_fold = false;
+  float ln_eps = 1e-5f;
   bool want_stats = false;     // output feeds a GroupNorm: emit its statistics from the epilogue
   float* out_stats = nullptr;  // storage for them when `out` is preallocated
   int tile = 0;
@@ -144,6 +149,9 @@ struct ConvOpts {
 Act alloc_act(Ctx& c, int B, int H, int W, int C, bool with_stats = false);
 // y = conv(x [| x2]) with the fused epilogue; returns the output view (bf16 unless out_f32)
 Act conv_fwd(Ctx& c, const ConvW& w, const Act& x, const Act* x2, const ConvOpts& o);
+// whether a LayerNorm-folded call of this layer on `rows` tokens would run (streaming kernel applicable and the shape
+// large enough for it to be the fastest choice: the 64 x 64 level from 16 images up)
+bool conv_ln_fold_available(const Ctx& c, const ConvW& w, int64_t rows);
 
 struct GNW { float* g = nullptr; float* b = nullptr; int C = 0; float eps = 1e-5f; };
 Act groupnorm_fwd(Ctx& c, const GNW& w, const Act& x, const Act* x2, bool silu, const float* film = nullptr,

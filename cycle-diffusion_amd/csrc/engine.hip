@@ -146,6 +146,7 @@ __global__ void k_pack_rows(const float* __restrict__ w, OutT* __restrict__ out,
 
 void ParamStore::load(hipStream_t st, const std::string& name, const float* host, int ndim,
                       const int64_t* shape) {
+  ++version;
   auto it = by_name_.find(name);
   CD_CHECK(it != by_name_.end(), "unknown parameter name '%s'", name.c_str());
   ParamDecl& d = *it->second;
@@ -266,6 +267,7 @@ Act conv_fwd(Ctx& c, const ConvW& w, const Act& x, const Act* x2, const ConvOpts
   }
   p.out = y.p; p.out_ld = y.ld; p.out_f32 = o.out_f32 ? 1 : 0;
   p.zeros = c.zeros; p.tile = o.tile;
+  if (o.ln_fold) { p.ln_fold = 1; p.ln_eps = o.ln_eps; p.tile = kLinStreamTile; }
   if (c.f32) {
     p.out_f32 = 1;
     launch_conv_gemm_f32(c.st, p);
@@ -280,6 +282,11 @@ Act conv_fwd(Ctx& c, const ConvW& w, const Act& x, const Act* x2, const ConvOpts
   }
   launch_conv_gemm(c.st, p);
   return y;
+}
+
+bool conv_ln_fold_available(const Ctx& c, const ConvW& w, int64_t rows) {
+  return !c.f32 && w.wfrag && w.KH == 1 && w.KW == 1 && w.Cpad == 320 && rows >= 65536 && rows % 32 == 0 &&
+         w.N % 64 == 0 && w.N <= 2560;
 }
 
 Act groupnorm_fwd(Ctx& c, const GNW& w, const Act& x, const Act* x2, bool silu, const float* film,

@@ -79,6 +79,9 @@ struct ConvGemmParams {
   // per channel over each 32-row block); null = off. Not available with GEGLU.
   float* stats = nullptr;
   const bf16_t* zeros = nullptr;  // >= 256 B of zeros (masked rows / padding taps)
+  // the rows of A are LayerNorm-ed (no gain / bias: those are folded into wgt / bias) inside the kernel; lin_stream only
+  int ln_fold = 0;
+  float ln_eps = 1e-5f;
   int tile = 0;                   // 0 = auto (tile configuration AND split factor from the autotuner)
   // split-K (deep-K layers whose output tiles cannot fill 256 CUs): K is cut in `splitk` ranges, fp32
   // partial tiles meet in sk_scratch and the last arrival sums them in split order. 0/1 = off.
@@ -110,10 +113,14 @@ struct LinStreamParams {
   bf16_t* out = nullptr; int ldo = 0;
   float* stats = nullptr;
   int M = 0, N = 0;
+  float ln_eps = 1e-5f;  // LayerNorm-folded variants
 };
 constexpr int kLinStreamTile = 30;
 bool lin_stream_supports(const ConvGemmParams& p);
 void launch_lin_stream(hipStream_t st, const ConvGemmParams& p);
+// w_out = w . diag(gamma) (16-bit), bias_out = bias + w . beta (fp32): the weights of a LayerNorm-folded layer
+void launch_fold_ln(hipStream_t st, const bf16_t* w, int ldw, const float* gamma, const float* beta, const float* bias,
+                    bf16_t* w_out, float* bias_out, int N, int Kc);
 // standard packed rows [N][ldw] (K = 320 used) -> fragment-major blocks [N / 32][20][64][8]
 void launch_pack_wfrag(hipStream_t st, const bf16_t* w, int ldw, bf16_t* out, int N);
 

@@ -102,7 +102,10 @@ __device__ __forceinline__ void touch4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
 
 // DBG (statistics variants only, selected by CYCLEDIFF_LIN_DBG for hardware bisection; 0 in the product):
 // 1 = no lgkmcnt wait after the write-back, 2 = no global statistics stores, 3 = no column-sum pass, 4 = no write-back
-template <int ACT, bool RESID, bool STATS, int DBG = 0>
+// LNF: LayerNorm folded in. The rows of A are normalised in registers when a strip's fragments become current - a lane
+// holds half of its row (160 values), the other half sits in lane ^ 32 - and the layer runs on weights that carry the
+// LayerNorm's gain and bias (k_fold_ln): y = ((x - mean) rstd) . (W gamma)^T + (b + W beta), attention.py:211-215.
+template <int ACT, bool RESID, bool STATS, int DBG = 0, bool LNF = false>
 __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr bool GEGLU = (ACT == ACT_GEGLU);
@@ -176,6 +179,33 @@ __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
 
   // ---- fragment registers: this strip's and the next strip's A (MFMA B operand: lane = row mi, k half `half`)
   bf16x8 af[NKS], afn[NKS];
+  // LayerNorm of the wave's 32 rows in place (fp32 statistics and arithmetic, one rounding back to 16 bits)
+  auto normalise_rows = [&]() __attribute__((always_inline)) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      float f[8];
+      unpack8(__builtin_bit_cast(uint4, af[ks]), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1 += f[e]; s2 = __builtin_fmaf(f[e], f[e], s2); }
+      __builtin_amdgcn_sched_barrier(0);  // one fragment at a time (160 unpacked values would not fit)
+    }
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    const float mean = s1 * (1.0f / K);
+    const float var = fmaxf(s2 * (1.0f / K) - mean * mean, 0.f);
+    const float rstd = __builtin_amdgcn_rsqf(var + p.ln_eps);
+    const float nmr = -mean * rstd;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      float f[8];
+      unpack8(__builtin_bit_cast(uint4, af[ks]), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = __builtin_fmaf(f[e], rstd, nmr);
+      af[ks] = __builtin_bit_cast(bf16x8, pack8_sat(f));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   // copy one landed A piece into the NEXT-strip registers (only the 4 waves whose rows it holds)
   auto take_a = [&](int j, int slot) {
     if ((j & 1) != (wave >> 2)) return;
@@ -264,6 +294,7 @@ __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
   }
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) af[ks] = afn[ks];
+  if (LNF) normalise_rows();
 
   f32x16 acc[2];
   // post-transpose lane mapping: pass ps covers rows (lane >> 2) + 16 ps, columns 8 (lane & 3) .. +8 of a 32-column
@@ -449,6 +480,7 @@ __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
     if (has_next) {
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) af[ks] = afn[ks];
+      if (LNF) normalise_rows();
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dead tail pieces
@@ -467,10 +499,27 @@ __global__ void k_pack_wfrag(const bf16_t* __restrict__ w, int ldw, bf16_t* __re
   }
 }
 
-template <int ACT, bool RESID, bool STATS, int DBG = 0>
+// LayerNorm gain / bias folded into the following linear layer: w_out[n][k] = w[n][k] gamma[k] (one more rounding to
+// 16 bits), bias_out[n] = bias[n] + sum_k w[n][k] beta[k] (fp32). One wave per output row.
+__global__ void k_fold_ln(const bf16_t* __restrict__ w, int ldw, const float* __restrict__ gamma,
+                          const float* __restrict__ beta, const float* __restrict__ bias, bf16_t* __restrict__ w_out,
+                          float* __restrict__ bias_out, int N, int Kc) {
+  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int k = lane; k < Kc; k += 64) {
+    const float x = bf2f(w[(int64_t)n * ldw + k]);
+    acc = __builtin_fmaf(x, beta[k], acc);
+    w_out[(int64_t)n * ldw + k] = f2bf(x * gamma[k]);
+  }
+  acc = wave_allsum(acc);
+  if (lane == 0) bias_out[n] = (bias ? bias[n] : 0.f) + acc;
+}
+
+template <int ACT, bool RESID, bool STATS, int DBG = 0, bool LNF = false>
 void launch_variant(hipStream_t st, const LinStreamParams& p, int grid) {
   static std::once_flag attr_once;
-  auto kern = k_lin_stream<ACT, RESID, STATS, DBG>;
+  auto kern = k_lin_stream<ACT, RESID, STATS, DBG, LNF>;
   std::call_once(attr_once, [&]() {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   });
@@ -512,6 +561,13 @@ void launch_lin_stream(hipStream_t st, const ConvGemmParams& c) {
   }
   const int nstrips = (p.M + 255) / 256;
   const int grid = nstrips < ncu ? nstrips : ncu;
+  if (c.ln_fold) {  // LayerNorm folded in: the feed-forward GEGLU projection and the plain projections behind norm1-3
+    p.ln_eps = c.ln_eps;
+    CD_CHECK(!c.resid && !c.stats, "lin_stream: a LayerNorm-folded layer has neither residual nor statistics");
+    if (c.act == ACT_GEGLU) launch_variant<ACT_GEGLU, false, false, 0, true>(st, p, grid);
+    else launch_variant<ACT_NONE, false, false, 0, true>(st, p, grid);
+    return;
+  }
   if (c.act == ACT_GEGLU) launch_variant<ACT_GEGLU, false, false>(st, p, grid);
   else if (c.resid && c.stats) launch_variant<ACT_NONE, true, true>(st, p, grid);
   else if (c.resid) launch_variant<ACT_NONE, true, false>(st, p, grid);
@@ -524,6 +580,12 @@ void launch_lin_stream(hipStream_t st, const ConvGemmParams& c) {
     else launch_variant<ACT_NONE, false, true>(st, p, grid);
   }
   else launch_variant<ACT_NONE, false, false>(st, p, grid);
+}
+
+void launch_fold_ln(hipStream_t st, const bf16_t* w, int ldw, const float* gamma, const float* beta, const float* bias,
+                    bf16_t* w_out, float* bias_out, int N, int Kc) {
+  hipLaunchKernelGGL(lin_detail::k_fold_ln, dim3((N + 3) / 4), dim3(256), 0, st, w, ldw, gamma, beta, bias, w_out,
+                     bias_out, N, Kc);
 }
 
 void launch_pack_wfrag(hipStream_t st, const bf16_t* w, int ldw, bf16_t* out, int N) {

@@ -33,6 +33,9 @@ struct STW {  // SpatialTransformer with one BasicTransformerBlock
   ConvW *qkv1 = nullptr, *qk1 = nullptr, *v1 = nullptr, *o1 = nullptr;
   ConvW *q2 = nullptr, *k2 = nullptr, *v2 = nullptr, *o2 = nullptr;
   ConvW *ff1 = nullptr, *ff2 = nullptr;
+  // LayerNorm-folded copies (320-channel level only): norm2 -> to_q of the cross-attention, norm3 -> the GEGLU
+  // projection. Rebuilt from the loaded tensors whenever the parameter store changes (UNetOpenAI::refresh_ln_folds)
+  ConvW *q2_ln = nullptr, *ff1_ln = nullptr;
   // context cache (step invariant)
   bf16_t* k2c = nullptr;  // [B*L][C]
   bf16_t* v2c = nullptr;  // [B*L][C] (token-major: k_attention transposes V tiles with LDS transpose reads)
@@ -76,6 +79,8 @@ class UNetOpenAI : public UNet {
   int add_res(const std::string& pfx, int cin, int cout, bool up, bool down);
   int add_st(const std::string& pfx, int C, int heads, int dh);
   int add_ab(const std::string& pfx, int C, int heads);
+  int folded_version_ = -1;
+  void refresh_ln_folds(Ctx& c);
   Act run_block(Ctx& c, const Block& b, Act h, const Act* skip, const float* proj, int proj_ld, bool t_shared);
   Act res_fwd(Ctx& c, const ResW& r, const Act& x, const Act* x2, const float* proj, int proj_ld, bool t_shared);
   Act st_fwd(Ctx& c, STW& s, const Act& x);
@@ -157,6 +162,10 @@ int UNetOpenAI::add_st(const std::string& pfx, int C, int heads, int dh) {
   s.o2 = make_conv(params, tb + ".attn2.to_out.0", C, C, 1, true, false, 2);
   s.ff1 = make_conv(params, tb + ".ff.net.0.proj", 8 * C, C, 1, true, /*geglu=*/true, 2);
   s.ff2 = make_conv(params, tb + ".ff.net.2", C, 4 * C, 1, true, false, 2);
+  if (s.q2->wfrag) {  // derived weights, not declared as parameters
+    s.q2_ln = params.new_conv(C, C, 1, 1, true);
+    s.ff1_ln = params.new_conv(8 * C, C, 1, 1, true, /*geglu=*/true);
+  }
   st_.push_back(s);
   return (int)st_.size() - 1;
 }
@@ -409,8 +418,14 @@ Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x) {
   }
   {  // cross-attention over the cached context K / V
     const size_t m2 = c.arena->mark();
-    Act n2 = layernorm_fwd(c, s.ln2, h);
-    Act q = conv_fwd(c, *s.q2, n2, nullptr, p0);
+    Act q;
+    if (s.q2_ln && conv_ln_fold_available(c, *s.q2_ln, h.rows())) {  // norm2 inside the projection kernel
+      ConvOpts pl; pl.pad = 0; pl.ln_fold = true;
+      q = conv_fwd(c, *s.q2_ln, h, nullptr, pl);
+    } else {
+      Act n2 = layernorm_fwd(c, s.ln2, h);
+      q = conv_fwd(c, *s.q2, n2, nullptr, p0);
+    }
     Act a = attention_fwd(c, q.p, q.ld, s.k2c, C, s.v2c, C, B, s.heads, T, ctx_L_, s.dh, scale, x.H, x.W,
                           /*q_log2=*/true);
     ConvOpts o; o.pad = 0; o.resid = &h; o.out = h.p; o.out_ld = h.ld;  // in-place residual update
@@ -419,8 +434,14 @@ Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x) {
   }
   {  // GEGLU feed-forward
     const size_t m2 = c.arena->mark();
-    Act n3 = layernorm_fwd(c, s.ln3, h);
-    Act g = conv_fwd(c, *s.ff1, n3, nullptr, p0);  // [B*T][4C]
+    Act g;  // [B*T][4C]
+    if (s.ff1_ln && conv_ln_fold_available(c, *s.ff1_ln, h.rows())) {  // norm3 inside the GEGLU projection kernel
+      ConvOpts pl; pl.pad = 0; pl.ln_fold = true;
+      g = conv_fwd(c, *s.ff1_ln, h, nullptr, pl);
+    } else {
+      Act n3 = layernorm_fwd(c, s.ln3, h);
+      g = conv_fwd(c, *s.ff1, n3, nullptr, p0);
+    }
     ConvOpts o; o.pad = 0; o.resid = &h; o.out = h.p; o.out_ld = h.ld;
     conv_fwd(c, *s.ff2, g, nullptr, o);
     c.arena->release(m2);
@@ -484,9 +505,26 @@ Act UNetOpenAI::run_block(Ctx& c, const Block& b, Act h, const Act* skip, const 
   return h;
 }
 
+// W' = W diag(gamma), b' = b + W beta for the LayerNorm-folded layers (attention.py:211-215: x + attn2(norm2(x)),
+// x + ff(norm3(x))), in both weight layouts; stream-ordered, a few microseconds, only after a parameter load
+void UNetOpenAI::refresh_ln_folds(Ctx& c) {
+  if (folded_version_ == params.version) return;
+  for (STW& s : st_) {
+    if (!s.q2_ln) continue;
+    struct { const ConvW* src; ConvW* dst; const LNW* ln; } jobs[2] = {{s.q2, s.q2_ln, &s.ln2}, {s.ff1, s.ff1_ln, &s.ln3}};
+    for (auto& j : jobs) {
+      launch_fold_ln(c.st, j.src->w, j.src->Ktot(), j.ln->g, j.ln->b, j.src->b, j.dst->w, j.dst->b, j.src->Npad,
+                     j.src->Cpad);
+      launch_pack_wfrag(c.st, j.dst->w, j.dst->Ktot(), j.dst->wfrag, j.dst->Npad);
+    }
+  }
+  folded_version_ = params.version;
+}
+
 void UNetOpenAI::forward(Ctx& c, const UNetIO& io) {
   const size_t mk0 = c.arena->mark();
   c.f32 = f32;
+  refresh_ln_folds(c);
   const int B = io.B, R = image_size;
   // ---- time embedding: sinusoid -> Linear -> SiLU -> Linear, then every ResBlock's
   //      emb_layers (SiLU -> Linear) in one launch (openaimodel.py:506-511,723-724,263)

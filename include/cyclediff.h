@@ -179,7 +179,8 @@ int cd_op_conv2d(cd_handle h, const float* x0, int C0, const float* x1, int C1, 
                  const float* bias, const float* rowvec, const float* resid, int act, int tile, float* y);
 /* the same convolution with the engine's 16-bit output (the product path's format; y still arrives as fp32 NCHW) and,
  * if `stats` is given, the fused GroupNorm statistics of the output: fp32 [B*Ho*Wo / 32][2][N] = per-channel sum |
- * sum of squares over each block of 32 rows. tile = 30 selects the streaming K = 320 linear kernel (lin_stream.hip). */
+ * sum of squares over each block of 32 rows. tile = 30 selects the streaming K = 320 linear kernel (lin_stream.hip);
+ * act | 0x400 additionally LayerNorm-s the input rows inside that kernel (statistics only, eps 1e-5; >= 65536 rows). */
 int cd_op_conv2d_16(cd_handle h, const float* x0, int C0, const float* x1, int C1, int B, int H, int W,
                     const void* packed_w, int N, int KH, int KW, int stride, int pad, int asym_pad, int up,
                     const float* bias, const float* rowvec, const float* resid, int act, int tile, float* y,

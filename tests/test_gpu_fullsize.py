@@ -65,6 +65,31 @@ def test_sd_unet_forward_full_size_vs_oracle(engine, report, sd_unet):
     assert rmax < 8e-3 * FMT and rmean < 8e-3 * FMT, (rmax, rmean)
 
 
+def test_sd_unet_forward_batch16_streaming_linears_vs_oracle(engine, report, sd_unet):
+    """The same U-Net at batch 16: the 64 x 64 level then has 65536 token rows, where the 320-channel linears run on
+    the streaming kernel (csrc/lin_stream.hip) and norm2 / norm3 are folded into the cross-attention query and GEGLU
+    projections (attention.py:211-215). Two of the sixteen samples are checked against the oracle, and sample 3 against
+    its own batch-1 forward (which takes the LayerNorm kernel + conv_gemm tiles)."""
+    net, sd = sd_unet
+    cfg = nets.OpenAIUNetCfg(in_channels=4, out_channels=4, model_channels=320, num_res_blocks=2,
+                             channel_mult=(1, 2, 4, 4), attn_ds=(4, 2, 1), num_heads=8,
+                             use_spatial_transformer=True, context_dim=768)
+    x, c, _ = _inputs(16, seed=9)
+    t = torch.full((16,), 501)
+    y = engine.unet_forward(net, x.cuda(), t.float().cuda(), c.cuda()).cpu()
+    assert torch.isfinite(y).all()
+    pick = [3, 12]
+    with torch.no_grad():
+        ref = nets.openai_unet(sd, cfg, x[pick], t[pick], c[pick])
+    rmax, rmean = _rel(y[pick], ref)
+    y1 = engine.unet_forward(net, x[3:4].cuda(), t[3:4].float().cuda(), c[3:4].cuda()).cpu()
+    bmax, bmean = _rel(y[3:4], y1)
+    report.add("fullsize/sd_unet_b16_streaming", rel_to_max=rmax, mean_rel=rmean, vs_batch1_rel_to_max=bmax,
+               vs_batch1_mean_rel=bmean)
+    assert rmax < 8e-3 * FMT and rmean < 8e-3 * FMT, (rmax, rmean)
+    assert bmax < 8e-3 * FMT, bmax
+
+
 def test_kl_f8_vae_full_size_vs_oracle(engine, report, sd_vae):
     """AutoencoderKL encode (posterior mean) and decode at 512x512 (autoencoder.py:324-333)."""
     net, sd = sd_vae

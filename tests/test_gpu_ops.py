@@ -220,6 +220,30 @@ def test_lin_stream(engine, report, case):
             assert (st_alt - want).abs().max().item() < 2e-3 * scale
 
 
+@pytest.mark.parametrize("geglu", [False, True], ids=["plain", "geglu"])
+def test_lin_stream_layernorm_fold(engine, report, geglu):
+    """LayerNorm folded into the projection (attention.py:211-215: attn2(norm2(x)), ff(norm3(x))): the kernel normalises
+    the rows in registers (statistics only), gain and bias travel in the weights: y = LN(x; gamma, beta) W^T + b =
+    ((x - mean) rstd) (W gamma)^T + (b + W beta). 65536 rows (the 64 x 64 level at batch 16)."""
+    g = torch.Generator().manual_seed(77 + int(geglu))
+    B, H, W, K = 16, 64, 64, 320
+    N = 2560 if geglu else 320
+    x = r16(torch.randn(B, K, H, W, generator=g) * 1.7 + 0.3 * torch.randn(B, 1, H, W, generator=g))
+    w = r16(torch.randn(N, K, generator=g) / math.sqrt(K))
+    bias = torch.randn(N, generator=g) * 0.5
+    gamma, beta = 1.0 + 0.2 * torch.randn(K, generator=g), 0.3 * torch.randn(K, generator=g)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, K)
+    ref = F.linear(F.layer_norm(rows, (K,), gamma, beta, 1e-5), w, bias)
+    if geglu:
+        val, gate = ref.chunk(2, dim=1)
+        ref = val * F.gelu(gate)
+    w_f = r16(w * gamma[None, :])             # what k_fold_ln produces
+    b_f = bias + w @ beta
+    got = _ops.conv2d16(engine, x, w_f[:, :, None, None], pad=0, bias=b_f, geglu=geglu, tile=30, act=0x400)
+    got = got.permute(0, 2, 3, 1).reshape(-1, ref.shape[1])
+    _check(report, "lin_stream/ln_fold_%s" % ("geglu" if geglu else "plain"), got, ref, rel=8e-3, mean=4e-3)
+
+
 GN_CASES = [("c320", 2, 320, 16, 16, 1e-5, True, False), ("c64", 2, 64, 8, 8, 1e-6, False, False),
             ("c2560", 1, 2560, 8, 8, 1e-5, True, False), ("c128_film", 2, 128, 16, 16, 1e-5, True, True),
             ("c32", 1, 32, 32, 32, 1e-6, True, False), ("c1920", 1, 1920, 16, 16, 1e-5, True, False),
