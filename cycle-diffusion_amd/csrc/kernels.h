@@ -124,10 +124,6 @@ void launch_fold_ln(hipStream_t st, const bf16_t* w, int ldw, const float* gamma
 // standard packed rows [N][ldw] (K = 320 used) -> fragment-major blocks [N / 32][20][64][8]
 void launch_pack_wfrag(hipStream_t st, const bf16_t* w, int ldw, bf16_t* out, int N);
 
-// ---------------------------------------------------------------- ping-pong 256 x 320 tile (conv_pp.hip, tile id 31)
-bool conv_pp_supports(const ConvGemmParams& p);
-void launch_conv_pp(hipStream_t st, const ConvGemmParams& p);
-
 // Optional per-launch timing of the dominant kernel family with HIP events recorded on the launch
 // stream (bench.py's roofline leg). flops = 2*M*N*K per launch (algorithmic, padding excluded except
 // the 3/4 -> 32 input-channel pad of conv_in).
