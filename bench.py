@@ -245,7 +245,8 @@ def main():
     ap.add_argument("--in-flight", type=int, default=1,
                     help="launch sets in flight per GPU: independent engine replicas (own HIP stream, workspace and "
                          "weights) driven by host threads")
-    ap.add_argument("--precision", default="", help="c5 / c5r only: fp32 (default, the reference's arithmetic) or fp16")
+    ap.add_argument("--precision", default="", help="c5 / c5r only: fp32 (default, the reference's arithmetic), fp32x3 (the fp32 network with its "
+                    "GroupNorm-fed convolutions as three-term split-fp16 GEMMs) or fp16 (throughput only: lossy for 'ddim')")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even at world size 1 (exercises the gather path on a 1-GPU box)")
     a = ap.parse_args()
@@ -278,7 +279,7 @@ def main():
     if a.precision:
         assert a.workload in ("c5", "c5r"), "--precision applies to the pixel-space workloads"
         args.gan.precision = a.precision
-        if a.precision != "fp32":  # throughput-only line: the wrapper refuses 16-bit 'ddim' unless asked by name
+        if a.precision not in ("fp32", "fp32x3"):  # throughput-only line: the wrapper refuses 16-bit 'ddim' unless asked by name
             args.gan.allow_lossy_ddim = True
     # Engine replicas: replica r owns stream r, its own engine (workspace, split-K scratch) and weights. With the
     # default coalescing one replica already keeps 32 images in flight (C2); more replicas only overlap kernel tails.
@@ -401,7 +402,9 @@ def main():
         n_launch, k_ms, k_flops = eng.prof_collect()
         eng.prof_enable(False)
         f32 = getattr(wrapper, "precision", "") == "fp32"
-        peak = PEAK_F32_TFLOPS if f32 else PEAK_TFLOPS
+        x3 = getattr(wrapper, "precision", "") == "fp32x3"
+        # split mode: algorithmic flops (2 M N K of the fp32 conv) against a third of the 16-bit MFMA peak
+        peak = PEAK_F32_TFLOPS if f32 else (PEAK_TFLOPS / 3.0 if x3 else PEAK_TFLOPS)
         ach = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         traffic = pmc_traffic_per_launch() if a.workload == "c2" else None
         fmt = "fp16" if eng.lib.cd_act_format() == 1 else "bf16"
@@ -409,7 +412,7 @@ def main():
             "metric": wl["metric"], "value": ips, "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp32" if f32 else fmt, "data": "synthetic",
+            "dtype": "fp32" if f32 else ("fp32 (3 x fp16 split products)" if x3 else fmt), "data": "synthetic",
             "config": {"workload": wl["name"], "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world, "steps_per_launch_set": C, "launch_sets_in_flight_per_gpu": n_rep,
                        "images_in_flight_per_gpu": B * C * n_rep,
@@ -419,12 +422,15 @@ def main():
                        "host_cpu_cores_used": host_cpu / dt,
                        "host_busiest_threads": ["%s %.2f" % (n, c) for c, n in busiest],
                        "storage": ("fp32 activations / weights, v_mfma_f32_32x32x2_f32 (the reference's arithmetic)" if f32
+                                   else "fp32 activations / weights; GroupNorm-fed convolutions as hi.wh + lo.wh + hi.wl on "
+                                        "v_mfma_f32_32x32x16_f16 (2^-22 per product), the rest on the fp32 path" if x3
                                    else "%s activations / weights, fp32 accumulate (BASELINE.json's C2 line says bf16: same "
                                         "width and MFMA rate; fp16 keeps the DPM-Encoder's 1/sigma amplification 8x smaller, "
                                         "DESIGN.md §5; bf16 is the CD_ACT_FP16=0 build)" % fmt),
                        "weights": wrapper.weights_origin, "flop_per_image": wl["flop_per_image"]},
             "roofline": {"bound": "mfma", "kernel": "k_conv_f32 (fp32 implicit GEMM)" if f32 else
-                         "k_conv_gemm (all tile instantiations)",
+                         ("k_conv_gemm on split operands (K x 3) + k_conv_f32 for raw-input convs; algorithmic flops, "
+                          "peak = 16-bit MFMA peak / 3") if x3 else "k_conv_gemm (all tile instantiations)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC, profiles/)",
                          "operating_point": "one launch set of %d steps, single stream, per-launch HIP events" % C,

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcyclediff.so")
 CD_NET_UNET_OPENAI, CD_NET_UNET_HO, CD_NET_VAE_KL, CD_NET_CLIP_TEXT, CD_NET_BERT_XTR = 1, 2, 3, 4, 5
 CD_NET_OCLIP_TEXT, CD_NET_OCLIP_VISION = 6, 7
 CD_SCHED_DDIM, CD_SCHED_DDPM = 0, 1
-CD_PREC_16, CD_PREC_F32 = 0, 1
+CD_PREC_16, CD_PREC_F32, CD_PREC_F32X3 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = 0, 1, 2, 3
 
 

@@ -81,9 +81,21 @@ struct cd_engine {
   ParamStore op_params;
   std::unique_ptr<KernelProfiler> prof;
   SplitKWorkspace splitk;  // split-K partial tiles + arrival counters of THIS engine's stream (conv_gemm.hip)
+  // CD_PREC_F32X3 range guard: one word of mapped host memory the split kernels set when a scaled activation / weight
+  // leaves the fp16 range; read (no stream drain needed) at every API entry and after cd_engine_synchronize
+  int* overflow_host = nullptr;
+  int* overflow_dev = nullptr;
+  void check_overflow() {
+    if (overflow_host && *(volatile int*)overflow_host) {
+      *(volatile int*)overflow_host = 0;
+      CD_CHECK(false, "CD_PREC_F32X3: a GroupNorm output or weight left the fp16 range of the split representation "
+                      "(|x| >= 4094 or |w| >= 255); results since the last synchronisation are invalid - run this "
+                      "network with CD_PREC_F32");
+    }
+  }
   Ctx ctx() {
     Ctx c; c.st = st; c.arena = &arena; c.zeros = zeros; c.gn_partial = gn_partial;
-    c.gn_partial_floats = gn_partial_floats;
+    c.gn_partial_floats = gn_partial_floats; c.overflow = overflow_dev;
     return c;
   }
 };
@@ -109,6 +121,7 @@ static void enter_engine(cd_engine* h) {
   if (!h) return;
   g_conv_splitk = h->splitk;
   g_conv_prof = (h->prof && h->prof->enabled) ? h->prof.get() : nullptr;
+  h->check_overflow();
 }
 
 #define CD_API_BEGIN try {
@@ -174,12 +187,16 @@ int cd_engine_create(void* hip_stream, size_t workspace_bytes, cd_handle* out) {
   HIP_CHECK(hipMalloc((void**)&h->gn_partial, h->gn_partial_floats * sizeof(float)));
   h->pacer.init();
   h->coef_staging.init();
+  HIP_CHECK(hipHostMalloc((void**)&h->overflow_host, 64, hipHostMallocMapped));
+  *h->overflow_host = 0;
+  HIP_CHECK(hipHostGetDevicePointer((void**)&h->overflow_dev, h->overflow_host, 0));
   *out = h.release();
   CD_API_END
 }
 
 int cd_engine_destroy(cd_handle h) {
   CD_API_BEGIN
+  if (h && h->overflow_host) *h->overflow_host = 0;  // nothing left to report to
   enter_engine(h);
   if (h) {
     (void)hipStreamSynchronize(h->st);
@@ -191,6 +208,7 @@ int cd_engine_destroy(cd_handle h) {
     if (h->gn_partial) (void)hipFree(h->gn_partial);
     h->pacer.destroy();
     h->coef_staging.destroy();
+    if (h->overflow_host) (void)hipHostFree(h->overflow_host);
     delete h;
   }
   CD_API_END
@@ -200,6 +218,7 @@ int cd_engine_synchronize(cd_handle h) {
   CD_API_BEGIN
   CD_CHECK(h, "null handle");
   h->pacer.wait_all(h->st);
+  h->check_overflow();
   CD_API_END
 }
 
@@ -249,6 +268,7 @@ int cd_net_create(cd_handle h, const cd_net_desc* d, int* net_id) {
     case CD_NET_OCLIP_VISION: n = make_clip_text(*d); break;
     default: CD_CHECK(false, "unknown net kind %d", d->kind);
   }
+  n->params.overflow = h->overflow_dev;
   h->nets.push_back(std::move(n));
   *net_id = (int)h->nets.size() - 1;
   CD_API_END

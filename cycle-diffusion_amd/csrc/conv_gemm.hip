@@ -452,7 +452,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
           for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
         }
       }
-      if (p.resid) {
+      if (p.resid && p.resid_f32) {
+        const float* rp = (const float*)p.resid + (int64_t)zb * p.o_bs + (int64_t)m * p.resid_ld + on;
+        if (nvalid == 8 && ((p.resid_ld & 3) == 0)) {
+          const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += rp[e];
+        }
+      } else if (p.resid) {
         const bf16_t* rp = p.resid + (int64_t)zb * p.o_bs + (int64_t)m * p.resid_ld + on;
         if (nvalid == 8 && ((p.resid_ld & 7) == 0)) {
           float rr[8];
@@ -857,7 +867,8 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
       snprintf(what, sizeof(what), "M%d N%d K%d k%d s%d%s%s z%d act%d | %s x%d", p.M, p.N, p.Ktot, p.KH, p.stride,
                p.up ? " up" : "", p.src1 ? " cat" : "", p.nbatch, p.act, ci->name, pk.splitk > 1 ? pk.splitk : 1);
     if (prof->verbose && !k64) strncat(what, " bk32", sizeof(what) - strlen(what) - 1);
-    prof->next_pair(&e0, &e1, 2.0 * (double)p.M * (double)p.N * (double)p.Ktot * (double)p.nbatch, what);
+    prof->next_pair(&e0, &e1, 2.0 * (double)p.M * (double)p.N * (double)p.Ktot * (double)p.nbatch * p.prof_flop_scale,
+                    what);
     (void)hipEventRecord(e0, st);
   }
   struct Closer {  // record the stop event on every exit path

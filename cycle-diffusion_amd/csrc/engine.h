@@ -36,6 +36,9 @@ struct Act {  // NHWC activation view: 16-bit elements, or fp32 when f32 is set 
   int B = 0, H = 0, W = 0, C = 0;
   int ld = 0;  // pixel stride (elements)
   bool f32 = false;
+  // fp32 path in the split-fp16 mode (CD_PREC_F32X3): p holds the fp16 pair [hi(C) | lo(C)] per pixel, ld = 2 * C
+  // (kernels.h kX3ActScale). Only GroupNorm outputs (and their 2x2 average pools) take this form; convs consume it
+  bool split = false;
   float* pf() const { return (float*)p; }
   // GroupNorm statistics of this tensor, written by the conv epilogue that produced it
   // ([B*H*W/32][2][C] fp32, ConvGemmParams::stats); stats_buf = storage, stats = valid content
@@ -48,6 +51,7 @@ struct Act {  // NHWC activation view: 16-bit elements, or fp32 when f32 is set 
 struct ConvW {  // packed conv / linear weight: 16-bit (or fp32 when f32) [Npad][KH*KW*Cpad], fp32 bias[N]
   bf16_t* w = nullptr;
   bf16_t* wfrag = nullptr;  // the same rows in MFMA-fragment-major order for lin_stream.hip (1x1, 320 input channels)
+  bf16_t* w3 = nullptr;     // CD_PREC_F32X3: fp16 [Npad][KH*KW][wh | wh | wl] (3 * Cpad per tap), from the fp32 rows in w
   bool f32 = false;
   float* b = nullptr;
   int N = 0, Cin = 0, Cpad = 0, KH = 1, KW = 1, Npad = 0;
@@ -81,6 +85,8 @@ class ParamStore {
  public:
   ~ParamStore();
   bool f32 = false;  // matrices are packed as fp32 (set by the network before it declares anything)
+  bool x3 = false;   // ... and additionally as three-term fp16 splits (CD_PREC_F32X3)
+  int* overflow = nullptr;  // host-visible word set when a split weight leaves the fp16 range (engine-owned)
   int version = 0;   // bumped by every load(): derived weights (LayerNorm folds) are rebuilt when it moves
   // allocate packed storage
   ConvW* new_conv(int N, int Cin, int KH, int KW, bool bias, bool geglu = false);
@@ -123,6 +129,8 @@ struct Ctx {
   float* gn_partial = nullptr;  // [B][S][G][2] scratch, sized for the largest GroupNorm
   size_t gn_partial_floats = 0;
   bool f32 = false;             // the running network executes in fp32 (Net::f32)
+  bool x3 = false;              // ... with its GroupNorm-fed convolutions as three-term fp16 GEMMs (Net::x3)
+  int* overflow = nullptr;      // host-visible word the split kernels set on a value outside the fp16 range
 };
 
 // shared building blocks -------------------------------------------------------------------
@@ -179,7 +187,8 @@ class Net {
   virtual ~Net() {}
   ParamStore params;
   cd_net_desc desc;
-  bool f32 = false;  // desc.precision == CD_PREC_F32
+  bool f32 = false;  // desc.precision is CD_PREC_F32 or CD_PREC_F32X3
+  bool x3 = false;   // desc.precision == CD_PREC_F32X3
   virtual int kind() const = 0;
 };
 

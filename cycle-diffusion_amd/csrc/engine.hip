@@ -46,6 +46,7 @@ ConvW* ParamStore::new_conv(int N, int Cin, int KH, int KW, bool bias, bool gegl
   c->w = (bf16_t*)dmalloc((size_t)c->Npad * c->Ktot() * (f32 ? sizeof(float) : sizeof(bf16_t)));
   if (!f32 && KH == 1 && KW == 1 && c->Cpad == 320)  // the streaming linear kernel reads fragment-major weights
     c->wfrag = (bf16_t*)dmalloc((size_t)c->Npad * c->Cpad * sizeof(bf16_t));
+  if (f32 && x3) c->w3 = (bf16_t*)dmalloc((size_t)c->Npad * c->Ktot() * 3 * sizeof(bf16_t));
   if (bias) c->b = (float*)dmalloc((size_t)c->Npad * sizeof(float));
   return c;
 }
@@ -190,6 +191,7 @@ void ParamStore::load(hipStream_t st, const std::string& name, const float* host
         hipLaunchKernelGGL(k_pack_rows<bf16_t>, dim3(grid), dim3(256), 0, st, staging_, c->w, t.rows, c->Cin, c->KH,
                            c->KW, c->Cpad, t.dst_row0, t.src_base, t.grp, t.grp_stride, t.geglu ? 1 : 0, c->N, t.scale);
       if (c->wfrag) launch_pack_wfrag(st, c->w, c->Ktot(), c->wfrag, c->Npad);  // whole matrix: rows may come in parts
+      if (c->w3) launch_pack_w3(st, (const float*)c->w, c->w3, c->Npad, c->KH * c->KW, c->Cpad, overflow);
     } else {
       // small: map on the host
       const int K = (t.kind == PackTarget::MATRIX_F32) ? t.K : 1;
@@ -230,10 +232,52 @@ Act alloc_act(Ctx& c, int B, int H, int W, int C, bool with_stats) {
   return a;
 }
 
+// CD_PREC_F32X3: x = [hi | lo] fp16 pairs (a GroupNorm output), weights [wh | wh | wl]: one 16-bit implicit GEMM
+// over the channel list [hi | lo | hi], fp32 bias / time-embedding row / residual / output (kernels.h kX3ActScale)
+static Act conv_split_fwd(Ctx& c, const ConvW& w, const Act& x, const ConvOpts& o) {
+  CD_CHECK(c.f32 && c.x3 && w.w3 && !w.geglu, "conv: split input outside the split-fp16 mode");
+  CD_CHECK(x.C == w.Cpad && x.ld == 2 * x.C, "conv: split input of %d channels (ld %d) against Cpad %d", x.C, x.ld, w.Cpad);
+  CD_CHECK(!o.ln_fold && (!o.resid || (o.resid->f32 && !o.resid->split)), "conv: split-mode operands");
+  ConvGemmParams p;
+  p.src0 = x.p; p.C0 = 2 * x.C; p.ld0 = x.ld;
+  p.src1 = x.p; p.C1 = x.C; p.ld1 = x.ld;
+  p.B = x.B; p.Hs = x.H; p.Ws = x.W; p.up = o.up ? 1 : 0;
+  p.Hin = o.up ? x.H * 2 : x.H; p.Win = o.up ? x.W * 2 : x.W;
+  p.KH = w.KH; p.KW = w.KW; p.stride = o.stride;
+  if (o.asym) { p.pad_t = 0; p.pad_l = 0; p.Hout = (p.Hin + 1 - w.KH) / o.stride + 1; p.Wout = (p.Win + 1 - w.KW) / o.stride + 1; }
+  else {
+    p.pad_t = o.pad; p.pad_l = o.pad;
+    p.Hout = (p.Hin + 2 * o.pad - w.KH) / o.stride + 1;
+    p.Wout = (p.Win + 2 * o.pad - w.KW) / o.stride + 1;
+  }
+  p.M = x.B * p.Hout * p.Wout;
+  p.wgt = w.w3; p.Ktot = 3 * w.Ktot(); p.N = w.N;
+  p.alpha = o.alpha * (1.0f / (kX3ActScale * kX3WgtScale)); p.bias = w.b;
+  p.rowvec = o.rowvec; p.rowvec_ld = o.rowvec_ld; p.rows_per_vec = o.rows_per_vec;
+  p.act = o.act;
+  Act y; y.B = x.B; y.H = p.Hout; y.W = p.Wout; y.C = w.N; y.f32 = true;
+  if (o.out) { y.p = (bf16_t*)o.out; y.ld = o.out_ld; }
+  else { y.ld = w.N; y.p = (bf16_t*)c.arena->alloc((size_t)p.M * w.N * 4); }
+  if (o.resid) {
+    CD_CHECK(o.resid->rows() == p.M && o.resid->C == w.N, "conv: residual shape mismatch");
+    p.resid = o.resid->p; p.resid_ld = o.resid->ld; p.resid_f32 = 1;
+  }
+  p.out = y.p; p.out_ld = y.ld; p.out_f32 = 1;
+  p.zeros = c.zeros; p.tile = o.tile;
+  p.prof_flop_scale = 1.0f / 3.0f;
+  launch_conv_gemm(c.st, p);
+  return y;
+}
+
 Act conv_fwd(Ctx& c, const ConvW& w, const Act& x, const Act* x2, const ConvOpts& o) {
+  if (x.split) {
+    CD_CHECK(!x2, "conv: a split activation cannot be concatenated");
+    return conv_split_fwd(c, w, x, o);
+  }
   ConvGemmParams p;
   CD_CHECK(w.f32 == c.f32 && x.f32 == c.f32 && (!x2 || x2->f32 == c.f32) && (!o.resid || o.resid->f32 == c.f32),
            "conv: operand precision does not match the running network");
+  CD_CHECK((!x2 || !x2->split) && (!o.resid || !o.resid->split), "conv: split activation as a second source / residual");
   p.src0 = x.p; p.C0 = round_up(x.C, 32); p.ld0 = x.ld;
   if (x2) {
     CD_CHECK(x2->B == x.B && x2->H == x.H && x2->W == x.W, "conv: concat sources differ in shape");
@@ -304,7 +348,8 @@ Act groupnorm_fwd(Ctx& c, const GNW& w, const Act& x, const Act* x2, bool silu, 
   Act y = alloc_act(c, x.B, x.H, x.W, C);
   p.y = y.p;
   if (c.f32) {
-    CD_CHECK(x.f32 && (!x2 || x2->f32), "groupnorm: operand precision");
+    CD_CHECK(x.f32 && (!x2 || x2->f32) && !x.split && (!x2 || !x2->split), "groupnorm: operand precision");
+    if (c.x3) { p.split_out = 1; p.overflow = c.overflow; y.split = true; y.ld = 2 * C; }  // same bytes as the fp32 tensor
     const size_t mk = c.arena->mark();
     void* ws = c.arena->alloc(groupnorm_f32_workspace(p.B, p.HW, C));
     launch_groupnorm_f32(c.st, p, ws);
@@ -325,6 +370,12 @@ Act groupnorm_fwd(Ctx& c, const GNW& w, const Act& x, const Act* x2, bool silu, 
 }
 
 Act avgpool2_fwd(Ctx& c, const Act& x) {
+  if (x.split) {
+    Act y = alloc_act(c, x.B, x.H / 2, x.W / 2, x.C);
+    y.split = true; y.ld = 2 * x.C;
+    launch_avgpool2_split(c.st, x.p, y.p, x.B, x.H, x.W, x.C, c.overflow);
+    return y;
+  }
   CD_CHECK(x.ld == x.C, "avgpool: dense input expected");
   Act y = alloc_act(c, x.B, x.H / 2, x.W / 2, x.C);
   if (c.f32) launch_avgpool2_f32(c.st, x.pf(), y.pf(), x.B, x.H, x.W, x.C);
@@ -332,14 +383,15 @@ Act avgpool2_fwd(Ctx& c, const Act& x) {
   return y;
 }
 Act upsample2_fwd(Ctx& c, const Act& x) {
-  CD_CHECK(x.ld == x.C, "upsample: dense input expected");
+  CD_CHECK(x.ld == x.C && !x.split, "upsample: dense input expected");
   Act y = alloc_act(c, x.B, x.H * 2, x.W * 2, x.C);
   if (c.f32) launch_upsample2_f32(c.st, x.pf(), y.pf(), x.B, x.H, x.W, x.C);
   else launch_upsample2(c.st, x.p, y.p, x.B, x.H, x.W, x.C);
   return y;
 }
 Act attention_f32_fwd(Ctx& c, const Act& qk, const Act& v, int H, int D, float scale, const float* obias) {
-  CD_CHECK(c.f32 && qk.f32 && v.f32 && qk.C == 2 * H * D && v.C == H * D, "attention_f32: operands");
+  CD_CHECK(c.f32 && qk.f32 && v.f32 && !qk.split && !v.split && qk.C == 2 * H * D && v.C == H * D,
+           "attention_f32: operands");
   Act o = alloc_act(c, qk.B, qk.H, qk.W, H * D);
   launch_attention_f32(c.st, qk.pf(), qk.ld, qk.pf() + H * D, qk.ld, v.pf(), v.ld, o.pf(), o.ld, qk.B, H,
                        qk.H * qk.W, D, scale, obias);

@@ -242,9 +242,19 @@ __global__ void k_gn_coef_f32(const double* __restrict__ part, int C, int HW, in
     coef[((int64_t)b * 2 + 1) * C + c] = d;
   }
 }
+// fp16 pair of a scaled fp32 value: hi = fp16(v), lo = fp16(v - hi) (the difference is exact in fp32); saturating
+__device__ inline void split_f16(float v, _Float16& hi, _Float16& lo, int* overflow) {
+  if (overflow && !(fabsf(v) <= 65504.f)) *overflow = 1;  // also NaN; reported by the engine (capi.hip check_overflow)
+  v = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+  hi = (_Float16)v;
+  lo = (_Float16)(v - (float)hi);
+}
+typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+
+template <bool SPLIT>
 __global__ void k_gn_apply_f32(const float* __restrict__ x0, const float* __restrict__ x1, int C0, int C1, int ld0,
                                int ld1, int HW, const float* __restrict__ coef, int silu, float* __restrict__ y,
-                               int64_t nvec) {
+                               int64_t nvec, int* overflow) {
   const int C = C0 + C1, C4 = C >> 2;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
     const int cv = (int)(i % C4);
@@ -261,7 +271,64 @@ __global__ void k_gn_apply_f32(const float* __restrict__ x0, const float* __rest
       const float t = v[e] * a[e] + d[e];
       o[e] = silu ? silu_acc(t) : t;
     }
-    *(f4*)(y + bp * C + c) = o;
+    if (SPLIT) {
+      h4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        _Float16 a_, b_;
+        split_f16(o[e] * kX3ActScale, a_, b_, overflow);
+        hi[e] = a_; lo[e] = b_;
+      }
+      _Float16* t = (_Float16*)y + bp * (2 * C);
+      *(h4*)(t + c) = hi;
+      *(h4*)(t + C + c) = lo;
+    } else {
+      *(f4*)(y + bp * C + c) = o;
+    }
+  }
+}
+__global__ void k_avgpool2_split(const _Float16* __restrict__ x, _Float16* __restrict__ y, int B, int H, int W, int C,
+                                 int* overflow) {
+  const int Ho = H / 2, Wo = W / 2, C4 = C >> 2;
+  const int64_t n = (int64_t)B * Ho * Wo * C4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % C4);
+    int64_t t = i / C4;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const _Float16* s = x + (((int64_t)b * H + oy * 2) * W + ox * 2) * (2 * C) + cv * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // F.avg_pool2d order: (a + b + c + d) * 0.25 on the 22-bit values hi + lo
+      const _Float16* sp = s + ((int64_t)(q >> 1) * W + (q & 1)) * (2 * C);
+      const h4 hi = *(const h4*)sp, lo = *(const h4*)(sp + C);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += (float)hi[e] + (float)lo[e];
+    }
+    h4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 a_, b_;
+      split_f16(acc[e] * 0.25f, a_, b_, overflow);
+      hi[e] = a_; lo[e] = b_;
+    }
+    _Float16* o = y + (((int64_t)b * Ho + oy) * Wo + ox) * (2 * C) + cv * 4;
+    *(h4*)o = hi;
+    *(h4*)(o + C) = lo;
+  }
+}
+// fp32 packed weights -> [wh | wh | wl] per filter tap (kernels.h kX3WgtScale)
+__global__ void k_pack_w3(const float* __restrict__ w, _Float16* __restrict__ w3, int64_t rows_taps, int Cpad,
+                          int* overflow) {
+  const int64_t n = rows_taps * Cpad;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cpad);
+    const int64_t rt = i / Cpad;
+    _Float16 hi, lo;
+    split_f16(w[i] * kX3WgtScale, hi, lo, overflow);
+    _Float16* o = w3 + rt * (3 * Cpad);
+    o[c] = hi; o[Cpad + c] = hi; o[2 * Cpad + c] = lo;
   }
 }
 
@@ -414,8 +481,23 @@ void launch_groupnorm_f32(hipStream_t st, const GroupNormParams& p, void* worksp
   hipLaunchKernelGGL(k_gn_coef_f32, dim3(p.G, p.B), dim3(64), 0, st, part, C, p.HW, S, p.G, p.eps, p.gamma, p.beta,
                      p.film, p.film_ld, coef);
   const int64_t nvec = (int64_t)p.B * p.HW * (C / 4);
-  hipLaunchKernelGGL(k_gn_apply_f32, dim3(ew_grid(nvec)), dim3(256), 0, st, x0, x1, p.C0, p.C1, p.ld0, p.ld1, p.HW,
-                     coef, p.silu, (float*)p.y, nvec);
+  if (p.split_out)
+    hipLaunchKernelGGL(k_gn_apply_f32<true>, dim3(ew_grid(nvec)), dim3(256), 0, st, x0, x1, p.C0, p.C1, p.ld0, p.ld1,
+                       p.HW, coef, p.silu, (float*)p.y, nvec, p.overflow);
+  else
+    hipLaunchKernelGGL(k_gn_apply_f32<false>, dim3(ew_grid(nvec)), dim3(256), 0, st, x0, x1, p.C0, p.C1, p.ld0, p.ld1,
+                       p.HW, coef, p.silu, (float*)p.y, nvec, nullptr);
+}
+void launch_pack_w3(hipStream_t st, const float* w, bf16_t* w3, int Npad, int taps, int Cpad, int* overflow) {
+  CD_CHECK(CD_ACT_FP16, "the split-fp16 mode of the fp32 path needs the fp16 build of the library");
+  const int64_t rt = (int64_t)Npad * taps;
+  hipLaunchKernelGGL(k_pack_w3, dim3(ew_grid(rt * Cpad)), dim3(256), 0, st, w, (_Float16*)w3, rt, Cpad,
+                     overflow);
+}
+void launch_avgpool2_split(hipStream_t st, const bf16_t* x, bf16_t* y, int B, int H, int W, int C, int* overflow) {
+  CD_CHECK(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "avgpool2_split: shape");
+  hipLaunchKernelGGL(k_avgpool2_split, dim3(ew_grid((int64_t)B * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, st,
+                     (const _Float16*)x, (_Float16*)y, B, H, W, C, overflow);
 }
 
 void launch_attention_f32(hipStream_t st, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,

@@ -71,6 +71,7 @@ struct ConvGemmParams {
   int rowvec_ld = 0, rows_per_vec = 1;
   const bf16_t* resid = nullptr;
   int resid_ld = 0;
+  int resid_f32 = 0;         // the residual is fp32 (the split-fp16 mode of the fp32 path, f32_path.hip)
   int act = ACT_NONE;
   void* out = nullptr;
   int out_ld = 0;
@@ -83,6 +84,7 @@ struct ConvGemmParams {
   int ln_fold = 0;
   float ln_eps = 1e-5f;
   int tile = 0;                   // 0 = auto (tile configuration AND split factor from the autotuner)
+  float prof_flop_scale = 1.f;    // KernelProfiler books 2*M*N*Ktot times this (1/3 for the three-term split GEMMs)
   // split-K (deep-K layers whose output tiles cannot fill 256 CUs): K is cut in `splitk` ranges, fp32
   // partial tiles meet in sk_scratch and the last arrival sums them in split order. 0/1 = off.
   int splitk = 0;
@@ -169,6 +171,8 @@ struct GroupNormParams {
   const float* film = nullptr;  // [B][2*C]: scale | shift
   int film_ld = 0;
   int silu = 0;
+  int split_out = 0;            // fp32 path only: y is the fp16 pair [B][HW][hi(C) | lo(C)] (CD_PREC_F32X3)
+  int* overflow = nullptr;      // ... set to 1 by any value outside the fp16 range after scaling (host-visible word)
   bf16_t* y = nullptr;          // [B][HW][C] dense
   float* partial = nullptr;     // workspace [B][S][G][2]
   int S = 0;
@@ -260,6 +264,18 @@ void launch_nchw_to_nhwc_f32(hipStream_t st, const float* x, float* y, int B, in
                              float shift);
 void launch_avgpool2_f32(hipStream_t st, const float* x, float* y, int B, int H, int W, int C);
 void launch_upsample2_f32(hipStream_t st, const float* x, float* y, int B, int H, int W, int C);
+// Split-fp16 mode of the fp32 path (precision CD_PREC_F32X3): a GroupNorm-ed activation x is kept as the fp16 pair
+// T = [hi | lo] per pixel, hi = fp16(s_a x), lo = fp16(s_a x - hi), and a weight as [wh | wh | wl] per filter tap
+// (scaled by s_w), so that one 16-bit implicit GEMM over the channel list [hi | lo | hi] with alpha = 1 / (s_a s_w)
+// yields x.w to 2^-22 (the lo.wl term is dropped). Exact powers of two; fp16 builds only.
+constexpr float kX3ActScale = 16.f;    // |x| < 4095 representable, full 22 bits down to |x| = 2^-6, 2^-28 absolute below
+constexpr float kX3WgtScale = 256.f;   // |w| < 255, full 22 bits down to |w| = 2^-10
+// fp32 packed weights [Npad][taps][Cpad] -> 16-bit [Npad][taps][3 * Cpad]
+// `overflow` (may be null): a host-visible word the kernels set to 1 when a scaled value leaves the fp16 range - the
+// engine turns it into an error at its next synchronisation point instead of returning saturated results.
+void launch_pack_w3(hipStream_t st, const float* w, bf16_t* w3, int Npad, int taps, int Cpad, int* overflow);
+// 2 x 2 average pool of a split activation [B][H][W][2C] -> [B][H/2][W/2][2C]
+void launch_avgpool2_split(hipStream_t st, const bf16_t* x, bf16_t* y, int B, int H, int W, int C, int* overflow);
 
 void launch_copy_strided_bf16(hipStream_t st, const bf16_t* src, int lds, bf16_t* dst, int ldd,
                               int64_t rows, int cols);

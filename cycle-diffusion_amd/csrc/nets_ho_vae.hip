@@ -301,8 +301,9 @@ class UNetHo : public UNet {
 
 UNetHo::UNetHo(const cd_net_desc& d) {
   desc = d;
-  f32 = d.precision == CD_PREC_F32;
-  params.f32 = f32;
+  f32 = d.precision == CD_PREC_F32 || d.precision == CD_PREC_F32X3;
+  x3 = d.precision == CD_PREC_F32X3;
+  params.f32 = f32; params.x3 = x3;
   ch_ = d.model_channels; nres_ = d.num_res_blocks; nlev_ = d.n_mult; temb_ch_ = 4 * ch_;
   image_size = d.image_size; out_channels = d.out_channels; in_cpad = round_up(d.in_channels, 32);
   CD_CHECK(ch_ % 32 == 0, "ch must be a multiple of 32");
@@ -376,7 +377,7 @@ UNetHo::UNetHo(const cd_net_desc& d) {
 
 void UNetHo::forward(Ctx& c, const UNetIO& io) {
   const size_t mk0 = c.arena->mark();
-  c.f32 = f32;
+  c.f32 = f32; c.x3 = x3;
   const int B = io.B, R = image_size;
   const int tB = io.t_shared ? 1 : B;
   float* sinu = (float*)c.arena->alloc((size_t)tB * ch_ * 4);
@@ -420,7 +421,7 @@ void UNetHo::forward(Ctx& c, const UNetIO& io) {
   ConvOpts oo; oo.out_f32 = true; oo.out = io.out; oo.out_ld = io.out_ld;
   conv_fwd(c, *cout_, n, nullptr, oo);
   c.arena->release(mk0);
-  c.f32 = false;
+  c.f32 = false; c.x3 = false;
 }
 
 }  // namespace

@@ -192,8 +192,9 @@ int UNetOpenAI::add_ab(const std::string& pfx, int C, int heads) {
 
 UNetOpenAI::UNetOpenAI(const cd_net_desc& d) {
   desc = d;
-  f32 = d.precision == CD_PREC_F32;
-  params.f32 = f32;
+  f32 = d.precision == CD_PREC_F32 || d.precision == CD_PREC_F32X3;
+  x3 = d.precision == CD_PREC_F32X3;
+  params.f32 = f32; params.x3 = x3;
   CD_CHECK(!(f32 && d.use_spatial_transformer), "CD_PREC_F32 covers U-Nets without SpatialTransformer blocks");
   mc_ = d.model_channels; hidden_ = 4 * mc_;
   image_size = d.image_size; out_channels = d.out_channels;
@@ -523,7 +524,7 @@ void UNetOpenAI::refresh_ln_folds(Ctx& c) {
 
 void UNetOpenAI::forward(Ctx& c, const UNetIO& io) {
   const size_t mk0 = c.arena->mark();
-  c.f32 = f32;
+  c.f32 = f32; c.x3 = x3;
   refresh_ln_folds(c);
   const int B = io.B, R = image_size;
   // ---- time embedding: sinusoid -> Linear -> SiLU -> Linear, then every ResBlock's
@@ -555,7 +556,7 @@ void UNetOpenAI::forward(Ctx& c, const UNetIO& io) {
   ConvOpts oo; oo.out_f32 = true; oo.out = io.out; oo.out_ld = io.out_ld;
   conv_fwd(c, *out_conv_, hn, nullptr, oo);
   c.arena->release(mk0);
-  c.f32 = false;
+  c.f32 = false; c.x3 = false;
 }
 
 }  // namespace

@@ -5,6 +5,9 @@ attributes .resolution .latent_dim .enforce_class_input.
 
 Precision: `[gan] precision = fp32` (default) runs the network in fp32 end to end on the engine's fp32 path - what the
 reference computes in (use_fp16=False) and what the 'ddim' chain needs to be reproducible (DESIGN.md §5);
+`precision = fp32x3` is the same fp32 network with its GroupNorm-fed convolutions (97 % of the FLOPs) evaluated as
+three-term split-fp16 products on the 16-bit matrix cores (2^-22 per product; 2.3x the fp32 throughput on C5, same
+parity floors; a value outside the fp16 range of the split raises instead of saturating);
 `precision = fp16` selects the 16-bit engine (about 6x the throughput; fine for sample_type 'ddpm').
 
 Unlike the reference, decode is batched: its 'ddim' branch compares [B,1,1,1] tensors and only runs
@@ -32,7 +35,8 @@ MODEL_TYPES = {
 }
 
 
-PRECISIONS = {"fp32": _ffi.CD_PREC_F32, "fp16": _ffi.CD_PREC_16, "16": _ffi.CD_PREC_16}
+# "fp32x3": the fp32 network with its large convolutions as three-term split-fp16 products (include/cyclediff.h)
+PRECISIONS = {"fp32": _ffi.CD_PREC_F32, "fp32x3": _ffi.CD_PREC_F32X3, "fp16": _ffi.CD_PREC_16, "16": _ffi.CD_PREC_16}
 
 
 def _desc(arch, precision=_ffi.CD_PREC_F32):
@@ -114,7 +118,14 @@ class DDPMDDIMWrapper(torch.nn.Module):
                                    last_uses_x0=False)
         z = z.view(bsz, -1)
         assert z.shape[1] == self.latent_dim
+        self._range_guard()
         return z
+
+    def _range_guard(self):
+        # 'fp32x3' keeps GroupNorm outputs as scaled fp16 pairs; a value outside that range raises at the engine's next
+        # synchronisation point rather than returning a saturated chain. One sync per chain of >= custom_steps forwards.
+        if self.precision == "fp32x3":
+            self.engine.synchronize()
 
     def generate(self, z, class_label):
         if self.enforce_class_input:
@@ -130,6 +141,7 @@ class DDPMDDIMWrapper(torch.nn.Module):
             for _ in range(self.refine_iterations):
                 nz = self._randn(self.refine_steps + 1, tuple(x.shape))
                 x = self.engine.pix_refine(self.net, self.sched.kind, x, self.sched.coef_refine(), noise=nz)
+        self._range_guard()
         return x
 
     def forward(self, z, class_label=None):

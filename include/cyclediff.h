@@ -30,7 +30,7 @@ typedef struct cd_engine* cd_handle;
 enum { CD_NET_UNET_OPENAI = 1, CD_NET_UNET_HO = 2, CD_NET_VAE_KL = 3, CD_NET_CLIP_TEXT = 4, CD_NET_BERT_XTR = 5,
        CD_NET_OCLIP_TEXT = 6, CD_NET_OCLIP_VISION = 7 };
 enum { CD_SCHED_DDIM = 0, CD_SCHED_DDPM = 1 };
-enum { CD_PREC_16 = 0, CD_PREC_F32 = 1 };
+enum { CD_PREC_16 = 0, CD_PREC_F32 = 1, CD_PREC_F32X3 = 2 };
 
 /* Architecture descriptor (the hyper-parameters of the reference's YAML / dict configs):
  *   UNET_OPENAI : ldm/modules/diffusionmodules/openaimodel.py:413-470 (SD v1, LDM text2img) and
@@ -67,7 +67,10 @@ typedef struct cd_net_desc {
   /* Storage / arithmetic of the network: CD_PREC_16 = 16-bit activations and weights, fp32 accumulate (default);
    * CD_PREC_F32 = fp32 activations, weights and matrix instructions - what the reference itself computes in
    * (`use_fp16=False`, improved_ddpm/script_util.py:15). U-Nets without SpatialTransformer blocks only: the
-   * pixel-space DDPMs of ddpm_ddim_wrapper.py, whose 'ddim' chain needs eps_hat at fp32 resolution. */
+   * pixel-space DDPMs of ddpm_ddim_wrapper.py, whose 'ddim' chain needs eps_hat at fp32 resolution;
+   * CD_PREC_F32X3 = the fp32 network with its GroupNorm-fed convolutions evaluated as three-term split-fp16 products on
+   * the 16-bit matrix cores (x = hi + lo, w = wh + wl; hi.wh + lo.wh + hi.wl, fp32 accumulate: 2^-22 per product
+   * instead of 2^-24; everything else as CD_PREC_F32). fp16 build of the library only. */
   int precision;
   /* VAE_KL only: > 0 selects the VQ first stage of the unconditional LDMs (VQModelInterface,
    * model/lib/latentdiff/ldm/models/autoencoder.py:264-282, `n_embed` codebook rows of width embed_dim): double_z = 0,

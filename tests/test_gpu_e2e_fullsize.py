@@ -198,7 +198,8 @@ def test_c2_fixture_triplet_folded_into_a_batch_of_32(report):
 
 
 # ---------------------------------------------------------------- BASELINE config 5 at its real size
-def test_c5_afhq_256_reduced_chain_vs_reference(report):
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
+def test_c5_afhq_256_reduced_chain_vs_reference(report, precision):
     """Two `i_DDPM('AFHQ')` networks at 256 x 256 through the model API main.py drives
     (model/unsupervised_translation.py:27-55: z = source.encode(image); img = target(z)), sample_type 'ddim' eta 0.1,
     REDUCED chain custom_steps 100 / es_steps 85 / refine_steps 10 (the reference cfg divided by 10), batch 1, on the
@@ -208,7 +209,10 @@ def test_c5_afhq_256_reduced_chain_vs_reference(report):
     Source and target are two DIFFERENT random-init networks, so the injected eps of one drives the other far out of
     the image range (the reference's image spans -42 ... +54; only 4 % of its pixels lie inside [0, 1]). The clamped
     PSNR of evaluation/utils.py:60-67 would therefore mostly compare saturated pixels; the stated tolerance is on the
-    RAW values: PSNR with peak 1 over the unclamped image >= 40 dB, i.e. rms error < 1e-2 on values of rms 10."""
+    RAW values: PSNR with peak 1 over the unclamped image >= 40 dB, i.e. rms error < 1e-2 on values of rms 10.
+
+    precision 'fp32x3': the same networks with their GroupNorm-fed convolutions as three-term split-fp16 products
+    (include/cyclediff.h CD_PREC_F32X3) - same floor."""
     from cycle_diffusion_amd.utils.config_utils import get_config
     from cycle_diffusion_amd.utils.program_utils import get_model
     path = os.path.join(gu.GOLD, "c5r_afhq256_e2e.npz")
@@ -222,12 +226,13 @@ def test_c5_afhq_256_reduced_chain_vs_reference(report):
     assert (args.gan.custom_steps, args.gan.es_steps, args.gan.refine_steps) == \
         (int(fx["custom_steps"]), int(fx["es_steps"]), int(fx["refine_steps"]))
     args.gan.noise_on_cpu = True
+    args.gan.precision = precision
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         model = get_model(args.model.name)(args).eval()
     names = json.loads(str(fx["names"]))
     for wrap, seed in ((model.source_gan_wrapper, seeds["source"]), (model.target_gan_wrapper, seeds["target"])):
-        assert wrap.precision == "fp32" and wrap.resolution == 256
+        assert wrap.precision == precision and wrap.resolution == 256
         sd = nets.synth_state_dict(names, seed)
         n, first = wrap.engine.load_state_dict(wrap.net, sd)
         assert n == 0, first
@@ -258,7 +263,7 @@ def test_c5_afhq_256_reduced_chain_vs_reference(report):
 
     ref, ref0 = torch.as_tensor(fx["img"]), torch.as_tensor(fx["img_unrefined"])
     p, p0 = raw_psnr(img.cpu(), ref), raw_psnr(img0.cpu(), ref0)
-    report.add("e2e/c5r_afhq256", raw_psnr_db=p, raw_psnr_unrefined_db=p0, clamped_psnr_db=gu.psnr(img.cpu(), ref),
+    report.add("e2e/c5r_afhq256" + ("" if precision == "fp32" else "_" + precision), raw_psnr_db=p, raw_psnr_unrefined_db=p0, clamped_psnr_db=gu.psnr(img.cpu(), ref),
                img_maxabs=(img.cpu() - ref).abs().max().item(), ref_absmax=ref.abs().max().item(),
                ref_rms=ref.pow(2).mean().sqrt().item(), xT_maxabs=xT, eps_rel_slots=eps_rel, z_norm_rel=zn_rel,
                reference_cpu_seconds=float(fx["cpu_seconds"]))

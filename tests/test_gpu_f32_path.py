@@ -19,6 +19,8 @@ from oracle import nets
 
 pytestmark = pytest.mark.gpu
 F32 = _ffi.CD_PREC_F32
+F32X3 = _ffi.CD_PREC_F32X3  # the same network, GroupNorm-fed convolutions as three-term split-fp16 products
+BOTH = pytest.mark.parametrize("prec", [F32, F32X3], ids=["fp32", "fp32x3"])
 
 
 def _rel(got, ref):
@@ -41,27 +43,29 @@ def tiny_iddpm_desc(precision=F32):
                          use_scale_shift_norm=True, resblock_updown=True, precision=precision)
 
 
-def test_f32_networks_vs_reference_fixtures(engine, report):
+@BOTH
+def test_f32_networks_vs_reference_fixtures(engine, report, prec):
     """improved-DDPM (FiLM, resblock up/down, legacy attention) and Ho-DDPM (asymmetric-pad downsample, concat
     skips, single-head attention) forwards against the reference modules' outputs: fp32 round-off only."""
     fx = gu.load("unet_tiny_iddpm")
-    net, _ = _load(engine, tiny_iddpm_desc(), fx)
+    net, _ = _load(engine, tiny_iddpm_desc(prec), fx)
     x, t = gu.rnd((2, 3, 32, 32), 3).cuda(), torch.tensor([3.0, 700.0]).cuda()
     y = engine.unet_forward(net, x, t)
     r1 = _rel(y, fx["y"])
     assert torch.equal(y, engine.unet_forward(net, x, t))  # deterministic
     fx2 = gu.load("unet_toy_ho")
-    net2, _ = _load(engine, cda.ho_ddpm_desc(32, 32, (1, 2, 2), 1, (16,), precision=F32), fx2)
+    net2, _ = _load(engine, cda.ho_ddpm_desc(32, 32, (1, 2, 2), 1, (16,), precision=prec), fx2)
     y2 = engine.unet_forward(net2, gu.rnd((1, 3, 32, 32), 6).cuda(), torch.tensor([490.0]).cuda())
     r2 = _rel(y2, fx2["y"])
-    report.add("f32/nets_vs_fixture", iddpm_rel_to_max=r1[0], iddpm_mean_rel=r1[1], ho_rel_to_max=r2[0], ho_mean_rel=r2[1])
+    report.add("f32/nets_vs_fixture" + ("_x3" if prec == F32X3 else ""), iddpm_rel_to_max=r1[0], iddpm_mean_rel=r1[1], ho_rel_to_max=r2[0], ho_mean_rel=r2[1])
     assert r1[0] < 2e-5 and r1[1] < 2e-5, r1
     assert r2[0] < 2e-5 and r2[1] < 2e-5, r2
 
 
-def test_f32_afhq_iddpm_full_size_vs_oracle(engine, report):
+@BOTH
+def test_f32_afhq_iddpm_full_size_vs_oracle(engine, report, prec):
     """BASELINE config 5's network at 256 x 256 on the fp32 path vs the CPU oracle."""
-    net = engine.create_net(cda.afhq_iddpm_desc(256, precision=F32))
+    net = engine.create_net(cda.afhq_iddpm_desc(256, precision=prec))
     sd = nets.synth_state_dict(engine.net_params(net), 2)
     assert engine.load_state_dict(net, sd)[0] == 0
     cfg = nets.OpenAIUNetCfg(in_channels=3, out_channels=6, model_channels=128, num_res_blocks=1,
@@ -73,7 +77,7 @@ def test_f32_afhq_iddpm_full_size_vs_oracle(engine, report):
         ref = nets.openai_unet(sd, cfg, x, t)
     y = engine.unet_forward(net, x.cuda(), t.cuda())
     r = _rel(y, ref)
-    report.add("f32/afhq_iddpm_fullsize", rel_to_max=r[0], mean_rel=r[1])
+    report.add("f32/afhq_iddpm_fullsize" + ("_x3" if prec == F32X3 else ""), rel_to_max=r[0], mean_rel=r[1])
     assert r[0] < 5e-5 and r[1] < 5e-5, r
 
 
@@ -115,31 +119,35 @@ def _chain(report, fx_name, desc):
         out1 = w(z)
     p0 = gu.psnr(out0, torch.as_tensor(fx["img"]))
     p1 = gu.psnr(out1, torch.as_tensor(fx["img_refined"]))
-    report.add("f32/" + fx_name, psnr_vs_reference=p0, psnr_refined_vs_reference=p1, psnr_vs_input=gu.psnr(out0, img),
+    report.add("f32/" + fx_name + ("_x3" if desc.precision == F32X3 else ""), psnr_vs_reference=p0, psnr_refined_vs_reference=p1, psnr_vs_input=gu.psnr(out0, img),
                eps_rel=zerr)
     return p0, p1, zerr
 
 
-def test_c1_chain_with_refinement_vs_reference(report):
+@BOTH
+def test_c1_chain_with_refinement_vs_reference(report, prec):
     """BASELINE config 1 network, 'ddim' eta 0.1, 50 + 50 steps, then the refinement loop (refine_steps = 10:
     re-noise to t = 9, ten random eta-1 steps; ddpm_ddim_wrapper.py:431-453) - cd_pix_refine."""
-    p0, p1, zerr = _chain(report, "c1_toy_ddpm_refine", cda.ho_ddpm_desc(32, 32, (1, 2, 2), 1, (16,), precision=F32))
+    p0, p1, zerr = _chain(report, "c1_toy_ddpm_refine", cda.ho_ddpm_desc(32, 32, (1, 2, 2), 1, (16,), precision=prec))
     assert p0 >= 40.0 and p1 >= 40.0, (p0, p1)
     assert max(zerr) < 1e-2, zerr
 
 
-def test_c5_reduced_chain_iddpm_vs_reference(report):
+@BOTH
+def test_c5_reduced_chain_iddpm_vs_reference(report, prec):
     """C5-shaped chain on the improved-DDPM architecture (6 -> 3 channel drop, ddpm_ddim_wrapper.py:237-238):
     custom_steps 100, es_steps 85, refine_steps 10."""
-    p0, p1, zerr = _chain(report, "c5_tiny_iddpm_chain", tiny_iddpm_desc())
+    p0, p1, zerr = _chain(report, "c5_tiny_iddpm_chain", tiny_iddpm_desc(prec))
     assert p0 >= 40.0 and p1 >= 40.0, (p0, p1)
     assert max(zerr) < 1e-2, zerr
 
 
-def test_f32_chain_is_bit_reproducible(engine):
-    """two identical encodes on the fp32 path give identical bits (no autotuner, no split-K on this path)"""
+@BOTH
+def test_f32_chain_is_bit_reproducible(engine, prec):
+    """two identical encodes on the fp32 path give identical bits (no autotuner, no split-K on this path; the split
+    mode's 16-bit GEMMs accumulate k-ascending in every tile configuration)"""
     fx = gu.load("c1_toy_ddpm")
-    net, _ = _load(engine, cda.ho_ddpm_desc(32, 32, (1, 2, 2), 1, (16,), precision=F32), fx)
+    net, _ = _load(engine, cda.ho_ddpm_desc(32, 32, (1, 2, 2), 1, (16,), precision=prec), fx)
     from cycle_diffusion_amd import schedule
     sch = schedule.PixelSchedule(20, 20, sample_type="ddim", eta=0.1)
     x0 = gu.rnd((2, 3, 32, 32), 21, 0.5).cuda()
@@ -150,3 +158,23 @@ def test_f32_chain_is_bit_reproducible(engine):
     # sample 0 alone == sample 0 in the batch of 2: the fp32 kernels' accumulation order does not depend on M
     z3 = engine.dpm_encode(net, sch.kind, x0[:1], sch.coef_encode(), noise=nz[:, :1].contiguous(), last_uses_x0=False)
     assert torch.equal(z3, z1[:1])
+
+
+def test_split_mode_range_guard_raises_instead_of_saturating(engine):
+    """CD_PREC_F32X3 keeps GroupNorm outputs as fp16 pairs scaled by 16: a value beyond +-4094 must surface as an error
+    at the next synchronisation point, and the engine must stay usable afterwards."""
+    fx = gu.load("unet_toy_ho")
+    net = engine.create_net(cda.ho_ddpm_desc(32, 32, (1, 2, 2), 1, (16,), precision=F32X3))
+    sd = dict(gu.weights(fx))
+    name = next(k for k in sd if k.endswith("norm1.bias"))
+    sd[name] = torch.full_like(torch.as_tensor(sd[name]), 5000.0)
+    assert engine.load_state_dict(net, sd)[0] == 0
+    x, t = gu.rnd((1, 3, 32, 32), 6).cuda(), torch.tensor([490.0]).cuda()
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        engine.unet_forward(net, x, t)
+        engine.synchronize()
+    sd[name] = torch.as_tensor(gu.weights(fx)[name])
+    assert engine.load_state_dict(net, sd)[0] == 0
+    y = engine.unet_forward(net, x, t)
+    engine.synchronize()
+    assert _rel(y, fx["y"])[0] < 1e-4
