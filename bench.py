@@ -45,6 +45,16 @@ WORKLOADS = {
                metric="images/sec, SD-v1.4 512px CycleDiffusion 100+100 steps, 1/2/4/8 MI355X",
                name="C2: Stable-Diffusion-v1.4-shaped U-Net + KL-f8 VAE, 512x512, custom_steps=99 "
                     "white_box_steps=100 eta=0.1 skip 0, 1 trial, encoder scale 1, decoder CFG 3"),
+    # the reference's actual SD experiment: per image 90 DPM-Encoder runs (15 trials x 6 skips, scale 1: one forward per
+    # step, ddim.py:550) and 540 decodes (6 scales; scale 1 decodes need one forward per step, the others two), then 540
+    # VAE decodes and a directional-CLIP ranking. sum over skips of (99 - skip) = 414 steps
+    "c2e": dict(cfg="experiments/translate_text2img256_stable_diffusion_stochastic_1.cfg", res=512, batch=1, text=True,
+                coalesce=1,
+                flop_per_image=F_VAE_ENC + 15 * 414 * F_UNET + 15 * 414 * 11 * F_UNET + 540 * F_VAE_DEC,
+                metric="images/sec, SD-v1.4 512px CycleDiffusion ensemble as the reference runs it: 15 trials x 6 skips x 6 "
+                       "decoder scales = 540 candidates per image, directional-CLIP ranked",
+                name="C2-ensemble: translate_text2img256_stable_diffusion_stochastic_1.cfg as written (custom_steps=99 "
+                     "white_box_steps=100 eta=0.1, n_trials=15, skip_steps [15..50], decoder scales [1..5]), 512x512"),
     "c3": dict(cfg="experiments/bench_ldm_c3.cfg", res=256, batch=16, text=True,
                flop_per_image=272.7e9 + 99 * 182.1e9 + 99 * 2 * 182.1e9 + 622.2e9,   # 55.0 TFLOP
                metric="images/sec, LDM text2img-large 256px CycleDiffusion 100+100 steps (BASELINE config 3)",
@@ -247,6 +257,10 @@ def main():
                          "weights) driven by host threads")
     ap.add_argument("--precision", default="", help="c5 / c5r only: fp32 (default, the reference's arithmetic), fp32x3 (the fp32 network with its "
                     "GroupNorm-fed convolutions as three-term split-fp16 GEMMs) or fp16 (throughput only: lossy for 'ddim')")
+    ap.add_argument("--trials", type=int, default=0, help="c2e only: override n_trials (the unfolded comparison runs a "
+                    "1-trial subset: the same 36 candidate chains per trial, one engine call each)")
+    ap.add_argument("--no-fold", action="store_true", help="c2e only: one engine call per ensemble member (the "
+                    "reference's loop) instead of folding the members that share (skip, scale) into one batch")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even at world size 1 (exercises the gather path on a 1-GPU box)")
     a = ap.parse_args()
@@ -281,6 +295,12 @@ def main():
         args.gan.precision = a.precision
         if a.precision not in ("fp32", "fp32x3"):  # throughput-only line: the wrapper refuses 16-bit 'ddim' unless asked by name
             args.gan.allow_lossy_ddim = True
+    ensemble = a.workload == "c2e"
+    if ensemble:
+        if a.trials:
+            args.gan.n_trials = a.trials
+        args.gan.fold_ensemble = not a.no_fold
+        args.gan.text_encoder = "clip"  # FrozenCLIPEmbedder on the engine (synthetic weights; hashing tokenizer)
     # Engine replicas: replica r owns stream r, its own engine (workspace, split-K scratch) and weights. With the
     # default coalescing one replica already keeps 32 images in flight (C2); more replicas only overlap kernel tails.
     n_rep = max(1, a.in_flight)
@@ -347,10 +367,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def mini_ensemble():
+        """the ensemble's engine calls at their real batch sizes but 4-step chains (skip 95) and two decoder scales:
+        warm-up (tunes the GEMM shapes of these batch sizes) and the event-instrumented roofline sample - a full ensemble
+        is ~10^2 s of GPU per image"""
+        keep = wrapper.skip_steps, wrapper.decoder_unconditional_guidance_scales
+        wrapper.skip_steps, wrapper.decoder_unconditional_guidance_scales = [95], [1, 3]
+        try:
+            gather(0, compute(0, 1))
+        finally:
+            wrapper.skip_steps, wrapper.decoder_unconditional_guidance_scales = keep
+        torch.cuda.synchronize(dev)
+
     # warm-up: every replica runs every launch-set size once (the first one tunes unseen GEMM shapes, the others
     # reuse the table), then whole sets until at least --warmup steps have run
     done = 0
-    for r in range(n_rep):
+    if ensemble:
+        mini_ensemble()
+        done = a.warmup
+    for r in range(n_rep if not ensemble else 0):
         for n in sorted(folded, reverse=True):
             gather(r, compute(r, n))
             torch.cuda.synchronize(dev)
@@ -395,7 +430,10 @@ def main():
     # its gathers) with per-launch HIP events on rank 0's engine stream; achieved = sum(2*M*N*K) / sum(durations)
     if rank == 0:
         eng.prof_enable(True)
-    gather(0, compute(0, C))
+    if ensemble:
+        mini_ensemble()
+    else:
+        gather(0, compute(0, C))
     sync()
     if rank == 0:
         ips = a.steps * B * world / dt
@@ -433,11 +471,27 @@ def main():
                           "peak = 16-bit MFMA peak / 3") if x3 else "k_conv_gemm (all tile instantiations)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC, profiles/)",
-                         "operating_point": "one launch set of %d steps, single stream, per-launch HIP events" % C,
+                         "operating_point": ("the ensemble's engine calls at their real batch sizes on 4-step chains (skip 95, "
+                                             "decoder scales 1 and 3), per-launch HIP events") if ensemble else
+                         "one launch set of %d steps, single stream, per-launch HIP events" % C,
                          "launches_per_step": n_launch / C, "kernel_ms_per_step": k_ms / C,
                          "algorithmic_tflop_per_step": k_flops / 1e12 / C,
                          "whole_path_frac": ips * wl["flop_per_image"] / 1e12 / (world * peak)},
         }
+        if ensemble:
+            n_cand = (wrapper.n_trials * len(wrapper.skip_steps) * len(wrapper.encoder_unconditional_guidance_scales) *
+                      len(wrapper.decoder_unconditional_guidance_scales))
+            full = 15 * 6 * 6
+            res["config"]["ensemble"] = {
+                "n_trials": wrapper.n_trials, "skip_steps": list(wrapper.skip_steps),
+                "decoder_scales": list(wrapper.decoder_unconditional_guidance_scales), "candidates_per_image": n_cand,
+                "folded": bool(wrapper.fold_ensemble), "max_fold": wrapper.MAX_FOLD,
+                "ranker": type(wrapper.ranker).__name__, "seconds_per_image": dt / (a.steps * B),
+                "seconds_per_candidate": dt / (a.steps * B * n_cand)}
+            if n_cand != full:  # a subset (--trials): the line's value is per image of THIS subset; scale by candidates
+                res["config"]["ensemble"]["images_per_s_at_540_candidates"] = ips * n_cand / full
+                res["config"]["flop_per_image"] = wl["flop_per_image"] * n_cand / full
+                res["roofline"]["whole_path_frac"] = ips * res["config"]["flop_per_image"] / 1e12 / (world * peak)
         if single_dt is not None:
             sv = a.single_steps * B * world / single_dt
             res["single_batch_value"] = sv  # images/s with ONE batch of B per launch set (`--coalesce 1`)

@@ -99,6 +99,12 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
                 raise RuntimeError("no text encoder: pass cond_stage / text_encoder, or load a checkpoint that has one")
             cond_stage = StandInTextEmbedder(udesc.context_dim)
         self.cond_stage = cond_stage
+        n_candidates = (n_trials or 1) * len(skip_steps or [0]) * len(encoder_unconditional_guidance_scales or [1]) * \
+            len(decoder_unconditional_guidance_scales or [1])
+        if ranker is None and n_candidates > 1:
+            # the reference builds its DirectionalCLIP unconditionally (sd_wrapper:140) and uses it when there is more
+            # than one candidate (:213-235): an ensemble config needs no extra key here either
+            ranker = "directional_clip"
         if ranker == "directional_clip":  # `[gan] ranker = directional_clip`: the reference's DirectionalCLIP on the engine
             from .ranker import DirectionalCLIPHIP
             rpath = ranker_path or os.environ.get("CYCLEDIFF_CLIP_RANKER")
@@ -233,7 +239,21 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
         def score(img):  # DirectionalCLIP returns (clip_score, dclip_score) and the reference ranks by the latter
             r = self.ranker(img, original_img, encode_text, decode_text)
             return r[1] if isinstance(r, (tuple, list)) else r
-        scores = torch.stack([score(img) for img in img_ensemble], dim=1)
+        if self.fold_ensemble:
+            # the reference scores candidate by candidate (sd_wrapper:216-227); candidates are independent samples of the
+            # ranker's batch, so they are scored MAX_FOLD images at a time (same per-sample scores, 1/32 of the calls)
+            bsz, per_call = original_img.shape[0], max(1, self.MAX_FOLD // original_img.shape[0])
+            parts = []
+            for j0 in range(0, len(img_ensemble), per_call):
+                chunk = img_ensemble[j0:j0 + per_call]
+                n = len(chunk)
+                sc = self.ranker(torch.cat(chunk, dim=0), original_img.repeat(n, 1, 1, 1), list(encode_text) * n,
+                                 list(decode_text) * n)
+                sc = sc[1] if isinstance(sc, (tuple, list)) else sc
+                parts.append(sc.view(n, bsz).t())
+            scores = torch.cat(parts, dim=1)
+        else:
+            scores = torch.stack([score(img) for img in img_ensemble], dim=1)
         best = torch.argmax(scores, dim=1)  # per-sample argmax over the ensemble (sd_wrapper:228-235)
         return torch.stack([img_ensemble[best[b].item()][b] for b in range(scores.shape[0])], dim=0)
 

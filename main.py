@@ -60,6 +60,8 @@ def main(argv=None):
     os.makedirs(a.output_dir, exist_ok=True)
     dev = torch.device("cuda", local)
     rows, grid_pairs = [], []
+    import time
+    t_start, n_done = time.perf_counter(), 0
     for step_idx in shard_indices(len(ds), a.per_device_eval_batch_size, world, rank):
         batch = collate([ds[i] for i in step_idx])
         kw = {"sample_id": batch["sample_id"].to(dev), "original_image": batch["original_image"].to(dev)}
@@ -67,6 +69,7 @@ def main(argv=None):
             kw.update(encode_text=batch["encode_text"], decode_text=batch["decode_text"])
         with torch.no_grad():
             (orig, img), _loss, _ = model(**kw)
+        n_done += img.shape[0]
         if a.grid and rank == 0 and len(grid_pairs) < 100:
             grid_pairs.append((orig.detach().clamp(0, 1).cpu(), img.detach().clamp(0, 1).cpu()))
         for j in range(img.shape[0]):
@@ -82,6 +85,8 @@ def main(argv=None):
             from PIL import Image
             Image.fromarray((g.permute(1, 2, 0).numpy() * 255 + 0.5).astype("uint8")).save(
                 os.path.join(a.output_dir, "%06d.png" % sid))
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t_start  # translation + per-image metrics + PNG writes of this rank
     if world > 1:
         gathered = [None] * world
         dist.all_gather_object(gathered, rows)
@@ -98,7 +103,7 @@ def main(argv=None):
         with open(os.path.join(a.output_dir, "metrics.json"), "w") as fh:
             json.dump({"summary": summary, "weights_origin": getattr(wrapper, "weights_origin", None),
                        "samples": rows}, fh, indent=1)
-        print(json.dumps({"n": len(rows), **summary}))
+        print(json.dumps({"n": len(rows), **summary, "seconds": wall, "images_per_s_this_rank": n_done / wall}))
     return 0
 
 
