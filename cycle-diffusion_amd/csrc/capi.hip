@@ -85,7 +85,6 @@ struct cd_engine {
   // leaves the fp16 range; read (no stream drain needed) at every API entry and after cd_engine_synchronize
   int* overflow_host = nullptr;
   int* overflow_dev = nullptr;
-  int* gn_arrivals = nullptr;  // fp32 GroupNorm arrival counters (f32_path.hip k_gn_stats_f32), zero between launches
   void check_overflow() {
     if (overflow_host && *(volatile int*)overflow_host) {
       *(volatile int*)overflow_host = 0;
@@ -96,7 +95,7 @@ struct cd_engine {
   }
   Ctx ctx() {
     Ctx c; c.st = st; c.arena = &arena; c.zeros = zeros; c.gn_partial = gn_partial;
-    c.gn_partial_floats = gn_partial_floats; c.overflow = overflow_dev; c.gn_arrivals = gn_arrivals;
+    c.gn_partial_floats = gn_partial_floats; c.overflow = overflow_dev;
     return c;
   }
 };
@@ -188,9 +187,6 @@ int cd_engine_create(void* hip_stream, size_t workspace_bytes, cd_handle* out) {
   HIP_CHECK(hipMalloc((void**)&h->gn_partial, h->gn_partial_floats * sizeof(float)));
   h->pacer.init();
   h->coef_staging.init();
-  HIP_CHECK(hipMalloc((void**)&h->gn_arrivals, kGnArrivalSlots * sizeof(int)));
-  HIP_CHECK(hipMemset(h->gn_arrivals, 0, kGnArrivalSlots * sizeof(int)));
-  HIP_CHECK(hipDeviceSynchronize());
   HIP_CHECK(hipHostMalloc((void**)&h->overflow_host, 64, hipHostMallocMapped));
   *h->overflow_host = 0;
   HIP_CHECK(hipHostGetDevicePointer((void**)&h->overflow_dev, h->overflow_host, 0));
@@ -213,7 +209,6 @@ int cd_engine_destroy(cd_handle h) {
     h->pacer.destroy();
     h->coef_staging.destroy();
     if (h->overflow_host) (void)hipHostFree(h->overflow_host);
-    if (h->gn_arrivals) (void)hipFree(h->gn_arrivals);
     delete h;
   }
   CD_API_END

@@ -131,7 +131,6 @@ struct Ctx {
   bool f32 = false;             // the running network executes in fp32 (Net::f32)
   bool x3 = false;              // ... with its GroupNorm-fed convolutions as three-term fp16 GEMMs (Net::x3)
   int* overflow = nullptr;      // host-visible word the split kernels set on a value outside the fp16 range
-  int* gn_arrivals = nullptr;   // kGnArrivalSlots zeroed counters for the fp32 GroupNorm's last-slab fold
 };
 
 // shared building blocks -------------------------------------------------------------------

@@ -350,7 +350,6 @@ Act groupnorm_fwd(Ctx& c, const GNW& w, const Act& x, const Act* x2, bool silu, 
   if (c.f32) {
     CD_CHECK(x.f32 && (!x2 || x2->f32) && !x.split && (!x2 || !x2->split), "groupnorm: operand precision");
     if (c.x3) { p.split_out = 1; p.overflow = c.overflow; y.split = true; y.ld = 2 * C; }  // same bytes as the fp32 tensor
-    p.arrivals = c.gn_arrivals;
     const size_t mk = c.arena->mark();
     void* ws = c.arena->alloc(groupnorm_f32_workspace(p.B, p.HW, C));
     launch_groupnorm_f32(c.st, p, ws);

@@ -168,16 +168,10 @@ __global__ __launch_bounds__(256) void k_conv_f32(ConvGemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------- GroupNorm(32)
-// pass 1: per (image, pixel slab) per-channel sums in fp64 (coalesced sweep, thread-fixed channel quad). The block that
-// arrives last for its image (arrival counter, agent-scope fences around it) folds the slabs and the channels of every
-// group in a fixed partition - 8 lanes per group, fixed fold order, so the result does not depend on which block that
-// is - and writes the per (image, channel) multiply-add pair; it leaves the counter at zero for the next launch.
-__global__ __launch_bounds__(256) void k_gn_stats_f32(const float* __restrict__ x0, const float* __restrict__ x1,
-                                                      int C0, int C1, int ld0, int ld1, int HW, int S,
-                                                      double* __restrict__ part, int* __restrict__ arrivals, int G,
-                                                      float eps, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, const float* __restrict__ film,
-                                                      int film_ld, float* __restrict__ coef) {
+// pass 1: per (image, pixel slab) per-channel sums in fp64 (coalesced sweep, thread-fixed channel quad)
+__global__ __launch_bounds__(256) void k_gn_partial_f32(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                        int C0, int C1, int ld0, int ld1, int HW, int S,
+                                                        double* __restrict__ part) {
   const int C = C0 + C1, C4 = C >> 2;
   const int b = blockIdx.y, s = blockIdx.x;
   const int ppb = (HW + S - 1) / S;
@@ -200,7 +194,6 @@ __global__ __launch_bounds__(256) void k_gn_stats_f32(const float* __restrict__ 
     }
   }
   __shared__ double sm[256 * 8];
-  __shared__ int last;
 #pragma unroll
   for (int e = 0; e < 4; ++e) { sm[tid * 8 + e] = sum[e]; sm[tid * 8 + 4 + e] = sq[e]; }
   __syncthreads();
@@ -212,39 +205,32 @@ __global__ __launch_bounds__(256) void k_gn_stats_f32(const float* __restrict__ 
     double* o = part + (((int64_t)b * S + s) * C4 + tid) * 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = a[e];
-    __threadfence();                            // release: the partial sums are visible device-wide before the count
+  }
+}
+// pass 2: fold slabs and the channels of a group -> per (image, channel) multiply-add pair
+__global__ void k_gn_coef_f32(const double* __restrict__ part, int C, int HW, int S, int G, float eps,
+                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                              const float* __restrict__ film, int film_ld, float* __restrict__ coef) {
+  const int b = blockIdx.y, g = blockIdx.x;
+  const int cpg = C / G, C4 = C >> 2;
+  __shared__ double red[2];
+  double s = 0, q = 0;  // fixed partition over the 64 lanes, fixed fold order: deterministic
+  for (int i = threadIdx.x; i < cpg * S; i += 64) {
+    const int c = g * cpg + i % cpg, sl = i / cpg;
+    const double* o = part + (((int64_t)b * S + sl) * C4 + (c >> 2)) * 8;
+    s += o[c & 3]; q += o[4 + (c & 3)];
+  }
+  for (int off = 32; off; off >>= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
+  if (threadIdx.x == 0) {
+    const double n = (double)cpg * HW;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0) var = 0;
+    red[0] = mean; red[1] = 1.0 / sqrt(var + (double)eps);
   }
   __syncthreads();
-  if (tid == 0) last = (atomicAdd(&arrivals[b], 1) == S - 1) ? 1 : 0;
-  __syncthreads();
-  if (!last) return;
-  __threadfence();                              // acquire: every other slab's sums
-  const int cpg = C / G;
-  float* stat = (float*)sm;                     // [G][2] mean | rstd (sm is free again)
-  __syncthreads();
-  for (int g0 = 0; g0 < G; g0 += 32) {
-    const int g = g0 + (tid >> 3), sub = tid & 7;
-    double sg = 0, qg = 0;
-    if (g < G) {
-      for (int i = sub; i < cpg * S; i += 8) {
-        const int c = g * cpg + i % cpg, sl = i / cpg;
-        const double* o = part + (((int64_t)b * S + sl) * C4 + (c >> 2)) * 8;
-        sg += o[c & 3]; qg += o[4 + (c & 3)];
-      }
-    }
-    for (int off = 4; off; off >>= 1) { sg += __shfl_xor(sg, off); qg += __shfl_xor(qg, off); }
-    if (g < G && sub == 0) {
-      const double n = (double)cpg * HW;
-      const double mean = sg / n;
-      double var = qg / n - mean * mean;
-      if (var < 0) var = 0;
-      stat[g * 2] = (float)mean; stat[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-  }
-  __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    const int g = c / cpg;
-    const float mean = stat[g * 2], rstd = stat[g * 2 + 1];
+  const float mean = (float)red[0], rstd = (float)red[1];
+  for (int c = g * cpg + threadIdx.x; c < (g + 1) * cpg; c += blockDim.x) {
     float a = rstd * gamma[c];
     float d = beta[c] - mean * a;
     if (film) {  // y = gn(x) * (1 + scale) + shift  (improved_ddpm/unet.py:253-257)
@@ -255,7 +241,6 @@ __global__ __launch_bounds__(256) void k_gn_stats_f32(const float* __restrict__ 
     coef[((int64_t)b * 2) * C + c] = a;
     coef[((int64_t)b * 2 + 1) * C + c] = d;
   }
-  if (tid == 0) arrivals[b] = 0;
 }
 // fp16 pair of a scaled fp32 value: hi = fp16(v), lo = fp16(v - hi) (the difference is exact in fp32); saturating
 __device__ inline void split_f16(float v, _Float16& hi, _Float16& lo, int* overflow) {
@@ -492,9 +477,9 @@ void launch_groupnorm_f32(hipStream_t st, const GroupNormParams& p, void* worksp
   float* coef = (float*)(part + (size_t)p.B * S * (C / 4) * 8);
   const float* x0 = (const float*)p.x;
   const float* x1 = (const float*)p.x1;
-  CD_CHECK(p.arrivals && p.B <= kGnArrivalSlots, "groupnorm_f32: arrival counters (batch %d)", p.B);
-  hipLaunchKernelGGL(k_gn_stats_f32, dim3(S, p.B), dim3(256), 0, st, x0, x1, p.C0, p.C1, p.ld0, p.ld1, p.HW, S, part,
-                     p.arrivals, p.G, p.eps, p.gamma, p.beta, p.film, p.film_ld, coef);
+  hipLaunchKernelGGL(k_gn_partial_f32, dim3(S, p.B), dim3(256), 0, st, x0, x1, p.C0, p.C1, p.ld0, p.ld1, p.HW, S, part);
+  hipLaunchKernelGGL(k_gn_coef_f32, dim3(p.G, p.B), dim3(64), 0, st, part, C, p.HW, S, p.G, p.eps, p.gamma, p.beta,
+                     p.film, p.film_ld, coef);
   const int64_t nvec = (int64_t)p.B * p.HW * (C / 4);
   if (p.split_out)
     hipLaunchKernelGGL(k_gn_apply_f32<true>, dim3(ew_grid(nvec)), dim3(256), 0, st, x0, x1, p.C0, p.C1, p.ld0, p.ld1,

@@ -173,7 +173,6 @@ struct GroupNormParams {
   int silu = 0;
   int split_out = 0;            // fp32 path only: y is the fp16 pair [B][HW][hi(C) | lo(C)] (CD_PREC_F32X3)
   int* overflow = nullptr;      // ... set to 1 by any value outside the fp16 range after scaling (host-visible word)
-  int* arrivals = nullptr;      // fp32 path: kGnArrivalSlots zeroed per-image counters (last slab folds the statistics)
   bf16_t* y = nullptr;          // [B][HW][C] dense
   float* partial = nullptr;     // workspace [B][S][G][2]
   int S = 0;
@@ -183,7 +182,6 @@ struct GroupNormParams {
   const float* pre0 = nullptr;
   const float* pre1 = nullptr;
 };
-constexpr int kGnArrivalSlots = 4096;
 int groupnorm_slabs(int B, int HW, int C);
 void launch_groupnorm(hipStream_t st, const GroupNormParams& p);
 
