@@ -226,15 +226,18 @@ def pmc_traffic_per_launch():
     """HBM-side bytes per k_conv_gemm launch from the committed rocprofv3 PMC passes (profiles/README.md):
     FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over the U-Net forwards of one coalesced C2 launch set (B'=32
     encode, B'=64 CFG decode), which launch equally often. None when the summaries are absent."""
-    vals = []
-    for name in ("r2b_conv_gemm_traffic_unet_b32.json", "r2b_conv_gemm_traffic_unet_b64.json"):
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
-        try:
-            with open(path) as fh:
-                vals.append(float(json.load(fh)["bytes_per_launch"]))
-        except (OSError, KeyError, ValueError):
-            return None
-    return sum(vals) / len(vals)
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for rnd in ("r3", "r2b"):  # the newest committed pair
+        vals = []
+        for b in (32, 64):
+            try:
+                with open(os.path.join(prof, "%s_conv_gemm_traffic_unet_b%d.json" % (rnd, b))) as fh:
+                    vals.append(float(json.load(fh)["bytes_per_launch"]))
+            except (OSError, KeyError, ValueError):
+                break
+        if len(vals) == 2:
+            return sum(vals) / len(vals)
+    return None
 
 
 def main():

@@ -1,4 +1,4 @@
-"""HBM-side traffic of the k_conv_gemm family from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes.
+"""HBM-side traffic of the k_conv_gemm family (incl. its streaming K = 320 member k_lin_stream) from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes.
 
   python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
 
@@ -16,7 +16,7 @@ def total(path, counter):
     n, s = 0, 0.0
     with open(path) as fh:
         for r in csv.DictReader(fh):
-            if r["Counter_Name"] == counter and "k_conv_gemm" in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and ("k_conv_gemm" in r["Kernel_Name"] or "k_lin_stream" in r["Kernel_Name"]):
                 n += 1
                 s += float(r["Counter_Value"])
     return n, s
@@ -25,7 +25,7 @@ def total(path, counter):
 nf, fetch_kb = total(sys.argv[1], "FETCH_SIZE")
 nw, write_kb = total(sys.argv[2], "WRITE_SIZE")
 out = {
-    "kernel": "k_conv_gemm (all tile instantiations)",
+    "kernel": "k_conv_gemm (all tile instantiations) + k_lin_stream (tile 30 of the same family)",
     "launches_fetch_pass": nf, "launches_write_pass": nw,
     "fetch_bytes_raw": fetch_kb * 1024.0, "fetch_bytes_corrected": 2.0 * fetch_kb * 1024.0,
     "write_bytes_raw": write_kb * 1024.0,

@@ -75,6 +75,9 @@ def _run(cls, fx_name, res, ctx_dim, report):
                                       ctx_c=w.cond_stage(["source"]).cuda(), guidance=1.0)
     x0_ref = torch.as_tensor(fx["x0"])
     cyc = (x_same.cpu() - x0_ref).abs()
+    with torch.no_grad():  # the same cycle in image space: both latents through the first-stage decoder
+        dec = lambda x: w.engine.vae_decode(w.vae, x.cuda().float(), scale=w.SCALE_FACTOR, out_mul=0.5, out_add=0.5).cpu()
+        cyc_img_db = gu.psnr(dec(x_same), dec(x0_ref))
     zc = z.cpu()
     slots = [int(s) for s in fx["z_sub_slots"]]
     zref = torch.as_tensor(fx["z_sub"])
@@ -93,6 +96,7 @@ def _run(cls, fx_name, res, ctx_dim, report):
                latent_ref_rms=lat_ref.pow(2).mean().sqrt().item(), xT_maxabs=xT_err,
                eps_rel_slots=dict(zip([str(s) for s in slots if s > 0], eps_rel)), z_norm_rel=zn_rel,
                cycle99_maxabs=cyc.max().item(), cycle99_rms=cyc.pow(2).mean().sqrt().item(),
+               cycle99_image_psnr_db=cyc_img_db,
                reference_cpu_seconds=float(fx["cpu_seconds"]))
     assert img.shape == (1, 3, res, res) and torch.isfinite(img).all()
     assert p >= PSNR_FLOOR, p
