@@ -100,12 +100,10 @@ __device__ __forceinline__ void touch4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
   asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
 }
 
-// DBG (statistics variants only, selected by CYCLEDIFF_LIN_DBG for hardware bisection; 0 in the product):
-// 1 = no lgkmcnt wait after the write-back, 2 = no global statistics stores, 3 = no column-sum pass, 4 = no write-back
 // LNF: LayerNorm folded in. The rows of A are normalised in registers when a strip's fragments become current - a lane
 // holds half of its row (160 values), the other half sits in lane ^ 32 - and the layer runs on weights that carry the
 // LayerNorm's gain and bias (k_fold_ln): y = ((x - mean) rstd) . (W gamma)^T + (b + W beta), attention.py:211-215.
-template <int ACT, bool RESID, bool STATS, int DBG = 0, bool LNF = false>
+template <int ACT, bool RESID, bool STATS, bool LNF = false>
 __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr bool GEGLU = (ACT == ACT_GEGLU);
@@ -438,19 +436,19 @@ __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
               __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_o, o_lane,
                                                      ((row0 + 16 * ps) * p.ldo + ncol0) * 2, 0);
             }
-            if (STATS && DBG != 4) {  // the final fp32 values go back to the transpose buffer for the column sums below
+            if (STATS) {  // the final fp32 values go back to the transpose buffer for the column sums below
               *(f32x4*)srow = (f32x4){v[0], v[1], v[2], v[3]};
               *(f32x4*)(srow + 4) = (f32x4){v[4], v[5], v[6], v[7]};
               // retire these stores before their source registers are reused: on hardware, without this wait, a few
               // waves per launch stored a wrong third dword in the NEXT pass (lanes 12-15 of every 16, this column
               // block only) although the instruction stream is correct - the following ds_read_b128 lands in the
-              // registers the pending ds_write_b128 takes its data from
-              if (DBG != 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              // registers the pending ds_write_b128 takes its data from (profiles/r3_lds_store_hazard_bisection.txt)
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
           }
           __builtin_amdgcn_sched_barrier(0);  // one (column block, pass) at a time: the temporaries must not pile up
         }
-        if (STATS && DBG != 3) {
+        if (STATS) {
           // per-channel sum / sum of squares over the wave's 32 rows (= one 32-row statistics block of
           // ConvGemmParams::stats): lane l sums column l & 31 over rows 16 (l >> 5) .. +16, the halves meet by DPP
           __builtin_amdgcn_wave_barrier();
@@ -461,7 +459,7 @@ __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
             s1 += x; s2 += x * x;
           }
           s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-          if (rows_ok && half2 == 0 && DBG != 2) {
+          if (rows_ok && half2 == 0) {
             float* sp = p.stats + (int64_t)((row0 + wave * 32) >> 5) * 2 * p.N + ncol0 + mi2;
             sp[0] = s1; sp[p.N] = s2;
           }
@@ -516,10 +514,10 @@ __global__ void k_fold_ln(const bf16_t* __restrict__ w, int ldw, const float* __
   if (lane == 0) bias_out[n] = (bias ? bias[n] : 0.f) + acc;
 }
 
-template <int ACT, bool RESID, bool STATS, int DBG = 0, bool LNF = false>
+template <int ACT, bool RESID, bool STATS, bool LNF = false>
 void launch_variant(hipStream_t st, const LinStreamParams& p, int grid) {
   static std::once_flag attr_once;
-  auto kern = k_lin_stream<ACT, RESID, STATS, DBG, LNF>;
+  auto kern = k_lin_stream<ACT, RESID, STATS, LNF>;
   std::call_once(attr_once, [&]() {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   });
@@ -564,21 +562,14 @@ void launch_lin_stream(hipStream_t st, const ConvGemmParams& c) {
   if (c.ln_fold) {  // LayerNorm folded in: the feed-forward GEGLU projection and the plain projections behind norm1-3
     p.ln_eps = c.ln_eps;
     CD_CHECK(!c.resid && !c.stats, "lin_stream: a LayerNorm-folded layer has neither residual nor statistics");
-    if (c.act == ACT_GEGLU) launch_variant<ACT_GEGLU, false, false, 0, true>(st, p, grid);
-    else launch_variant<ACT_NONE, false, false, 0, true>(st, p, grid);
+    if (c.act == ACT_GEGLU) launch_variant<ACT_GEGLU, false, false, true>(st, p, grid);
+    else launch_variant<ACT_NONE, false, false, true>(st, p, grid);
     return;
   }
   if (c.act == ACT_GEGLU) launch_variant<ACT_GEGLU, false, false>(st, p, grid);
   else if (c.resid && c.stats) launch_variant<ACT_NONE, true, true>(st, p, grid);
   else if (c.resid) launch_variant<ACT_NONE, true, false>(st, p, grid);
-  else if (c.stats) {
-    static const int dbg = [] { const char* e = getenv("CYCLEDIFF_LIN_DBG"); return e ? atoi(e) : 0; }();
-    if (dbg == 1) launch_variant<ACT_NONE, false, true, 1>(st, p, grid);
-    else if (dbg == 2) launch_variant<ACT_NONE, false, true, 2>(st, p, grid);
-    else if (dbg == 3) launch_variant<ACT_NONE, false, true, 3>(st, p, grid);
-    else if (dbg == 4) launch_variant<ACT_NONE, false, true, 4>(st, p, grid);
-    else launch_variant<ACT_NONE, false, true>(st, p, grid);
-  }
+  else if (c.stats) launch_variant<ACT_NONE, false, true>(st, p, grid);
   else launch_variant<ACT_NONE, false, false>(st, p, grid);
 }
 
