@@ -325,16 +325,19 @@ def test_attention(engine, report, case, vt):
 
 
 @pytest.mark.parametrize("vt", [False, True], ids=["v_token_major", "v_transposed"])
-@pytest.mark.parametrize("case", ["wide", "spike", "cross_spike"])
+@pytest.mark.parametrize("case", ["wide", "spike", "cross_spike", "wide_long", "spike_long"])
 def test_attention_deferred_max(engine, report, case, vt):
     """The attention kernel keeps a stale reference maximum and only moves it when a row's scores outgrow it by 2^8
     (attn.hip). The move is a rare, data-dependent branch: bounded random scores never take it after the first
     tile, so these inputs force it - a wide score distribution (log2-unit std ~6: the maximum of almost every row
     grows past the threshold several times over 16 tiles) and single spiked keys late in the sequence, placed so
-    that some rows of a 32-query wave move their maximum while their neighbours do not."""
+    that some rows of a 32-query wave move their maximum while their neighbours do not. The *_long cases (1024 queries,
+    V pre-transposed) run on the 256-query (8-wave) workgroups of the 64 x 64 level."""
     g = torch.Generator().manual_seed(23)
     B, H, D = 1, 2, 40
-    Tq, Tk = (512, 1024) if case != "cross_spike" else (256, 77)
+    long_case = case.endswith("_long")
+    case = case.replace("_long", "")
+    Tq, Tk = (1024 if long_case else 512, 1024) if case != "cross_spike" else (256, 77)
     C = H * D
     amp = 2.0 if case == "wide" else 1.0
     q = torch.randn(B, Tq, C, generator=g) * amp
@@ -354,7 +357,8 @@ def test_attention_deferred_max(engine, report, case, vt):
     ref = (att @ vh).transpose(1, 2).reshape(B, Tq, C).float()
     got = _ops.attention(engine, q, k, v, H, scale, v_transposed=vt)
     f = 1.0 if engine.lib.cd_act_format() == 1 else 8.0  # measured: rel_to_max 4-10e-4, mean_rel 3-5e-4 (fp16)
-    _check(report, "attention_deferred_max/%s/%s" % (case, "vt" if vt else "v"), got, ref, rel=4e-3 * f, mean=2e-3 * f)
+    _check(report, "attention_deferred_max/%s%s/%s" % (case, "_long" if long_case else "", "vt" if vt else "v"), got, ref,
+           rel=4e-3 * f, mean=2e-3 * f)
 
 
 @pytest.mark.parametrize("vt", [False, True], ids=["v_token_major", "v_transposed"])
