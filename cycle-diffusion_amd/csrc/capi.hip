@@ -411,6 +411,7 @@ void run_unet(cd_engine* h, SamplerState& s, int step) {
   if (s.f32) launch_nchw_to_nhwc_f32(h->st, s.xt, (float*)s.xin, s.B, s.C, s.HW, s.cpad, 1.f, 0.f);
   UNetIO io;
   io.xin = s.xin; io.B = s.Bn; io.tab = s.tab; io.step = step; io.t_shared = true;
+  io.cfg_dup = s.cfg;
   io.out = s.eh; io.out_ld = s.out_ld;
   s.u->forward(c, io);
 }

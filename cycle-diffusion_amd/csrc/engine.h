@@ -206,6 +206,10 @@ struct UNetIO {
   const StepCoef* tab = nullptr; const int* step_ptr = nullptr; int step = 0;
   const float* t_explicit = nullptr;  // [B] device, or null
   bool t_shared = true;               // all samples share one timestep -> embed once
+  // classifier-free-guidance batch [uncond B/2 | cond B/2] built from ONE x_t (ddim.py:553-559 th.cat([x] * 2)): rows
+  // B/2 .. B-1 of xin repeat rows 0 .. B/2-1 and only the cross-attention context differs, so everything ahead of the
+  // first cross-attention may be computed once for B/2 rows and duplicated
+  bool cfg_dup = false;
   float* out = nullptr;               // fp32 [B*H*W][out_ld]
   int out_ld = 0;
 };

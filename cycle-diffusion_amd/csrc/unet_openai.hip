@@ -83,7 +83,9 @@ class UNetOpenAI : public UNet {
   void refresh_ln_folds(Ctx& c);
   Act run_block(Ctx& c, const Block& b, Act h, const Act* skip, const float* proj, int proj_ld, bool t_shared);
   Act res_fwd(Ctx& c, const ResW& r, const Act& x, const Act* x2, const float* proj, int proj_ld, bool t_shared);
-  Act st_fwd(Ctx& c, STW& s, const Act& x);
+  // dup: x holds HALF of a classifier-free-guidance batch (UNetIO::cfg_dup); everything ahead of the cross-attention runs
+  // on it, then the token stream and the block input are duplicated and the rest runs on 2 * x.B rows
+  Act st_fwd(Ctx& c, STW& s, const Act& x, bool dup = false);
   Act ab_fwd(Ctx& c, const ABW& a, const Act& x);
  public:
   ~UNetOpenAI() override { for (void* p : ctx_allocs_) (void)hipFree(p); }
@@ -387,13 +389,26 @@ void UNetOpenAI::set_context(Ctx& c, const bf16_t* ctx, int B, int L) {
   }
 }
 
-Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x) {
-  const int B = x.B, T = x.H * x.W, C = s.C;
-  Act out = alloc_act(c, B, x.H, x.W, C, /*with_stats=*/true);
+// rows [0, n) of src -> rows [0, n) and [n, 2n) of dst (dense, `cols` 16-bit elements per row)
+static void dup_rows(Ctx& c, const bf16_t* src, bf16_t* dst, int64_t n, int cols) {
+  launch_copy_strided_bf16(c.st, src, cols, dst, cols, n, cols);
+  launch_copy_strided_bf16(c.st, src, cols, dst + n * cols, cols, n, cols);
+}
+
+Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x_in, bool dup) {
+  int B = x_in.B;
+  const int T = x_in.H * x_in.W, C = s.C;
+  Act out = alloc_act(c, dup ? 2 * B : B, x_in.H, x_in.W, C, /*with_stats=*/true);
+  Act x = x_in;
+  if (dup) {  // the block input at full batch: residual of proj_out (lives as long as the block's output)
+    CD_CHECK(x_in.ld == C, "transformer block: dense input expected");
+    x = alloc_act(c, 2 * B, x_in.H, x_in.W, C);
+    dup_rows(c, x_in.p, x.p, (int64_t)B * T, C);
+  }
   const size_t mk = c.arena->mark();
-  CD_CHECK(s.k2c && ctx_B_ == B, "cross-attention context not set for batch %d", B);
+  CD_CHECK(s.k2c && ctx_B_ == (dup ? 2 * B : B), "cross-attention context not set for batch %d", dup ? 2 * B : B);
   ConvOpts p0; p0.pad = 0;
-  Act n = groupnorm_fwd(c, s.norm, x, nullptr, false);
+  Act n = groupnorm_fwd(c, s.norm, x_in, nullptr, false);
   Act h = conv_fwd(c, *s.proj_in, n, nullptr, p0);  // tokens [B*T][C]
   const float scale = 1.0f / sqrtf((float)s.dh);
   {  // self-attention
@@ -416,6 +431,12 @@ Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x) {
     ConvOpts o; o.pad = 0; o.resid = &h; o.out = h.p; o.out_ld = h.ld;  // in-place residual update:
     conv_fwd(c, *s.o1, a, nullptr, o);  // each element is read then written by the same lane
     c.arena->release(m2);
+  }
+  if (dup) {  // from here on the two halves see different contexts
+    Act h2 = alloc_act(c, 2 * B, x_in.H, x_in.W, C);
+    dup_rows(c, h.p, h2.p, (int64_t)B * T, C);
+    h = h2;
+    B *= 2;
   }
   {  // cross-attention over the cached context K / V
     const size_t m2 = c.arena->mark();
@@ -543,8 +564,36 @@ void UNetOpenAI::forward(Ctx& c, const UNetIO& io) {
   Act x; x.p = (bf16_t*)io.xin; x.B = B; x.H = R; x.W = R; x.C = in_cpad; x.ld = in_cpad; x.f32 = f32;
   std::vector<Act> hs;
   Act h = x;
-  for (const Block& b : in_blocks_) {
-    h = run_block(c, b, h, nullptr, proj, proj_ld, io.t_shared);
+  size_t first_full = 0;  // first input block that runs at the full batch
+  // Classifier-free-guidance batch built from one x_t: conv_in, the first ResBlock and the first transformer block up
+  // to its self-attention output see identical rows in both halves (the context enters at the cross-attention): they run
+  // once on B / 2 rows (CYCLEDIFF_CFG_SHARE=0 turns this off for A/B runs). Per-row arithmetic is unchanged.
+  static const bool cfg_share = [] { const char* e = getenv("CYCLEDIFF_CFG_SHARE"); return !(e && e[0] == '0'); }();
+  if (io.cfg_dup && cfg_share && !f32 && io.t_shared && B % 2 == 0 && in_blocks_.size() >= 2 &&
+      in_blocks_[0].layers.size() == 1 && in_blocks_[0].layers[0].kind == Layer::CONV_IN &&
+      in_blocks_[1].layers.size() == 2 && in_blocks_[1].layers[0].kind == Layer::RES &&
+      in_blocks_[1].layers[1].kind == Layer::ST) {
+    const int Bh = B / 2;
+    Act xh = x; xh.B = Bh;
+    Act h0 = run_block(c, in_blocks_[0], xh, nullptr, proj, proj_ld, true);  // [Bh] conv_in output
+    // the skip connection of the last output block needs it at full batch (with its GroupNorm statistics)
+    Act h0f = alloc_act(c, B, h0.H, h0.W, h0.C, /*with_stats=*/h0.stats != nullptr);
+    CD_CHECK(h0.ld == h0.C, "conv_in output: dense tensor expected");
+    dup_rows(c, h0.p, h0f.p, h0.rows(), h0.C);
+    if (h0.stats) {
+      dup_rows(c, (const bf16_t*)h0.stats, (bf16_t*)h0f.stats_buf, (h0.rows() / 32) * 2, h0.C * 2);  // fp32 as 2 x 16 bit
+      h0f.stats = h0f.stats_buf;
+    }
+    hs.push_back(h0f);
+    const Layer& lr = in_blocks_[1].layers[0];
+    const Layer& lt = in_blocks_[1].layers[1];
+    Act hr = res_fwd(c, res_[lr.idx], h0, nullptr, proj, proj_ld, true);
+    h = st_fwd(c, st_[lt.idx], hr, /*dup=*/true);
+    hs.push_back(h);
+    first_full = 2;
+  }
+  for (size_t bi = first_full; bi < in_blocks_.size(); ++bi) {
+    h = run_block(c, in_blocks_[bi], h, nullptr, proj, proj_ld, io.t_shared);
     hs.push_back(h);
   }
   h = run_block(c, mid_, h, nullptr, proj, proj_ld, io.t_shared);
