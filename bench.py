@@ -468,7 +468,11 @@ def main():
                                    else "%s activations / weights, fp32 accumulate (BASELINE.json's C2 line says bf16: same "
                                         "width and MFMA rate; fp16 keeps the DPM-Encoder's 1/sigma amplification 8x smaller, "
                                         "DESIGN.md §5; bf16 is the CD_ACT_FP16=0 build)" % fmt),
-                       "weights": wrapper.weights_origin, "flop_per_image": wl["flop_per_image"]},
+                       "weights": wrapper.weights_origin, "flop_per_image": wl["flop_per_image"],
+                       # whole_path_frac prices the REFERENCE's work per image; the engine itself launches ~2 % less on
+                       # classifier-free-guidance decodes (shared prefix, DESIGN.md 7 r3 f) - roofline.achieved counts
+                       # what was launched
+                       "flop_per_image_basis": "reference algorithm: every U-Net forward in full"},
             "roofline": {"bound": "mfma", "kernel": "k_conv_f32 (fp32 implicit GEMM)" if f32 else
                          ("k_conv_gemm on split operands (K x 3) + k_conv_f32 for raw-input convs; algorithmic flops, "
                           "peak = 16-bit MFMA peak / 3") if x3 else "k_conv_gemm (all tile instantiations)",
