@@ -408,7 +408,8 @@ SamplerState setup_sampler(cd_engine* h, int net, const float* ctx_c, const floa
 
 void run_unet(cd_engine* h, SamplerState& s, int step) {
   Ctx c = h->ctx();
-  if (s.f32) launch_nchw_to_nhwc_f32(h->st, s.xt, (float*)s.xin, s.B, s.C, s.HW, s.cpad, 1.f, 0.f);
+  if (s.f32)
+    launch_nchw_to_nhwc_f32(h->st, s.xt, (float*)s.xin, s.B, s.C, s.HW, s.cpad, 1.f, 0.f, s.u->x3 ? 1 : 0, h->overflow_dev);
   UNetIO io;
   io.xin = s.xin; io.B = s.Bn; io.tab = s.tab; io.step = step; io.t_shared = true;
   io.cfg_dup = s.cfg;
@@ -436,7 +437,7 @@ int cd_unet_forward(cd_handle h, int net, const float* x, const float* t, const 
     u->set_context(c, cx, B, ctx_len);
   }
   bf16_t* xin = (bf16_t*)h->arena.alloc((size_t)B * HW * u->in_cpad * (u->f32 ? 4 : 2));
-  if (u->f32) launch_nchw_to_nhwc_f32(h->st, x, (float*)xin, B, C, HW, u->in_cpad, 1.f, 0.f);
+  if (u->f32) launch_nchw_to_nhwc_f32(h->st, x, (float*)xin, B, C, HW, u->in_cpad, 1.f, 0.f, u->x3 ? 1 : 0, h->overflow_dev);
   else launch_nchw_to_nhwc(h->st, x, xin, B, C, HW, u->in_cpad, 1.f, 0.f, 0);
   float* eh = (float*)h->arena.alloc((size_t)B * HW * Co * 4);
   UNetIO io; io.xin = xin; io.B = B; io.t_explicit = t; io.t_shared = false; io.out = eh; io.out_ld = Co;

@@ -227,7 +227,7 @@ int ParamStore::missing(std::string* first) const {
 Act alloc_act(Ctx& c, int B, int H, int W, int C, bool with_stats) {
   Act a; a.B = B; a.H = H; a.W = W; a.C = C; a.ld = C; a.f32 = c.f32;
   a.p = (bf16_t*)c.arena->alloc((size_t)B * H * W * C * (c.f32 ? sizeof(float) : sizeof(bf16_t)));
-  if (!c.f32 && with_stats && ((H * W) % 32) == 0)
+  if ((!c.f32 || c.x3) && with_stats && ((H * W) % 32) == 0)  // fp32 path: only its split mode emits statistics
     a.stats_buf = (float*)c.arena->alloc((size_t)(B * H * W / 32) * 2 * C * sizeof(float));
   return a;
 }
@@ -265,6 +265,13 @@ static Act conv_split_fwd(Ctx& c, const ConvW& w, const Act& x, const ConvOpts& 
   p.out = y.p; p.out_ld = y.ld; p.out_f32 = 1;
   p.zeros = c.zeros; p.tile = o.tile;
   p.prof_flop_scale = 1.0f / 3.0f;
+  if (((p.Hout * p.Wout) % 32) == 0) {  // the consumer's GroupNorm statistics from the epilogue, as on the 16-bit path
+    if (o.out && o.out_stats) y.stats_buf = o.out_stats;
+    else if (!o.out && o.want_stats)
+      y.stats_buf = (float*)c.arena->alloc((size_t)(p.M / 32) * 2 * w.N * sizeof(float));
+    p.stats = y.stats_buf;
+    y.stats = y.stats_buf;
+  }
   launch_conv_gemm(c.st, p);
   return y;
 }
@@ -350,6 +357,10 @@ Act groupnorm_fwd(Ctx& c, const GNW& w, const Act& x, const Act* x2, bool silu, 
   if (c.f32) {
     CD_CHECK(x.f32 && (!x2 || x2->f32) && !x.split && (!x2 || !x2->split), "groupnorm: operand precision");
     if (c.x3) { p.split_out = 1; p.overflow = c.overflow; y.split = true; y.ld = 2 * C; }  // same bytes as the fp32 tensor
+    if (x.stats && x.ld == x.C && (!x2 || (x2->stats && x2->ld == x2->C))) {  // written by the split convs' epilogues
+      p.pre0 = x.stats;
+      p.pre1 = x2 ? x2->stats : nullptr;
+    }
     const size_t mk = c.arena->mark();
     void* ws = c.arena->alloc(groupnorm_f32_workspace(p.B, p.HW, C));
     launch_groupnorm_f32(c.st, p, ws);

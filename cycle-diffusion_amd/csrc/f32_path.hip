@@ -242,6 +242,57 @@ __global__ void k_gn_coef_f32(const double* __restrict__ part, int C, int HW, in
     coef[((int64_t)b * 2 + 1) * C + c] = d;
   }
 }
+// CD_PREC_F32X3: the producing convolutions' epilogues already wrote per-channel sums over every 32-row block of the
+// tensor (ConvGemmParams::stats, fp32): grid (G, B) folds them in fp64, in a fixed order, straight into the per
+// (image, channel) multiply-add pair - no pass over the tensor itself (replaces k_gn_partial_f32 + k_gn_coef_f32)
+__global__ __launch_bounds__(256) void k_gn_fold_f32(const float* __restrict__ pre0, const float* __restrict__ pre1,
+                                                     int C0, int C1, int HW, int G, float eps,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ film, int film_ld,
+                                                     float* __restrict__ coef) {
+  __shared__ double rs[256], rq[256];
+  const int C = C0 + C1;
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / G;
+  const int nb = HW >> 5;
+  const int items = nb * cpg;
+  double a = 0, q = 0;
+  for (int it = tid; it < items; it += 256) {
+    const int rb = it / cpg, c = g * cpg + (it - rb * cpg);
+    const int64_t blk = (int64_t)b * nb + rb;
+    if (c < C0) {
+      const float* sp = pre0 + blk * 2 * C0 + c;
+      a += (double)sp[0]; q += (double)sp[C0];
+    } else {
+      const float* sp = pre1 + blk * 2 * C1 + (c - C0);
+      a += (double)sp[0]; q += (double)sp[C1];
+    }
+  }
+  rs[tid] = a; rq[tid] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {  // fixed-order tree: deterministic
+    if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
+    __syncthreads();
+  }
+  const double n = (double)cpg * HW;
+  const double mean_d = rs[0] / n;
+  double var = rq[0] / n - mean_d * mean_d;
+  if (var < 0) var = 0;
+  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (tid < cpg) {
+    const int c = g * cpg + tid;
+    float ca = rstd * gamma[c];
+    float cd = beta[c] - mean * ca;
+    if (film) {  // y = gn(x) * (1 + scale) + shift  (improved_ddpm/unet.py:253-257)
+      const float* fl = film + (int64_t)b * film_ld;
+      const float sc = 1.f + fl[c];
+      ca *= sc; cd = cd * sc + fl[C + c];
+    }
+    coef[((int64_t)b * 2) * C + c] = ca;
+    coef[((int64_t)b * 2 + 1) * C + c] = cd;
+  }
+}
+
 // fp16 pair of a scaled fp32 value: hi = fp16(v), lo = fp16(v - hi) (the difference is exact in fp32); saturating
 __device__ inline void split_f16(float v, _Float16& hi, _Float16& lo, int* overflow) {
   if (overflow && !(fabsf(v) <= 65504.f)) *overflow = 1;  // also NaN; reported by the engine (capi.hip check_overflow)
@@ -391,6 +442,23 @@ __global__ void k_nchw_to_nhwc_f32(const float* __restrict__ x, float* __restric
     y[i] = (c < C) ? x[((int64_t)b * C + c) * HW + pix] * scale + shift : 0.f;
   }
 }
+// the same into the split form [pixel][hi(Cpad) | lo(Cpad)] of CD_PREC_F32X3 (the U-Net input feeds conv_in as a
+// three-term product too)
+__global__ void k_nchw_to_nhwc_split(const float* __restrict__ x, _Float16* __restrict__ y, int B, int C, int HW,
+                                     int Cpad, float scale, float shift, int* overflow) {
+  const int64_t n = (int64_t)B * HW * Cpad;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cpad);
+    const int64_t bp = i / Cpad;
+    const int b = (int)(bp / HW);
+    const int pix = (int)(bp - (int64_t)b * HW);
+    const float v = (c < C) ? x[((int64_t)b * C + c) * HW + pix] * scale + shift : 0.f;
+    _Float16 hi, lo;
+    split_f16(v * kX3ActScale, hi, lo, overflow);
+    y[bp * (2 * Cpad) + c] = hi;
+    y[bp * (2 * Cpad) + Cpad + c] = lo;
+  }
+}
 __global__ void k_avgpool2_f32(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
   const int Ho = H / 2, Wo = W / 2, C4 = C >> 2;
   const int64_t n = (int64_t)B * Ho * Wo * C4;
@@ -477,9 +545,14 @@ void launch_groupnorm_f32(hipStream_t st, const GroupNormParams& p, void* worksp
   float* coef = (float*)(part + (size_t)p.B * S * (C / 4) * 8);
   const float* x0 = (const float*)p.x;
   const float* x1 = (const float*)p.x1;
-  hipLaunchKernelGGL(k_gn_partial_f32, dim3(S, p.B), dim3(256), 0, st, x0, x1, p.C0, p.C1, p.ld0, p.ld1, p.HW, S, part);
-  hipLaunchKernelGGL(k_gn_coef_f32, dim3(p.G, p.B), dim3(64), 0, st, part, C, p.HW, S, p.G, p.eps, p.gamma, p.beta,
-                     p.film, p.film_ld, coef);
+  if (p.pre0 && (p.C1 == 0 || p.pre1) && (p.HW % 32) == 0 && C / p.G <= 256) {
+    hipLaunchKernelGGL(k_gn_fold_f32, dim3(p.G, p.B), dim3(256), 0, st, p.pre0, p.pre1, p.C0, p.C1, p.HW, p.G, p.eps,
+                       p.gamma, p.beta, p.film, p.film_ld, coef);
+  } else {
+    hipLaunchKernelGGL(k_gn_partial_f32, dim3(S, p.B), dim3(256), 0, st, x0, x1, p.C0, p.C1, p.ld0, p.ld1, p.HW, S, part);
+    hipLaunchKernelGGL(k_gn_coef_f32, dim3(p.G, p.B), dim3(64), 0, st, part, C, p.HW, S, p.G, p.eps, p.gamma, p.beta,
+                       p.film, p.film_ld, coef);
+  }
   const int64_t nvec = (int64_t)p.B * p.HW * (C / 4);
   if (p.split_out)
     hipLaunchKernelGGL(k_gn_apply_f32<true>, dim3(ew_grid(nvec)), dim3(256), 0, st, x0, x1, p.C0, p.C1, p.ld0, p.ld1,
@@ -508,9 +581,13 @@ void launch_attention_f32(hipStream_t st, const float* q, int ldq, const float* 
 }
 
 void launch_nchw_to_nhwc_f32(hipStream_t st, const float* x, float* y, int B, int C, int HW, int Cpad, float scale,
-                             float shift) {
-  hipLaunchKernelGGL(k_nchw_to_nhwc_f32, dim3(ew_grid((int64_t)B * HW * Cpad)), dim3(256), 0, st, x, y, B, C, HW, Cpad,
-                     scale, shift);
+                             float shift, int split, int* overflow) {
+  if (split)
+    hipLaunchKernelGGL(k_nchw_to_nhwc_split, dim3(ew_grid((int64_t)B * HW * Cpad)), dim3(256), 0, st, x, (_Float16*)y,
+                       B, C, HW, Cpad, scale, shift, overflow);
+  else
+    hipLaunchKernelGGL(k_nchw_to_nhwc_f32, dim3(ew_grid((int64_t)B * HW * Cpad)), dim3(256), 0, st, x, y, B, C, HW, Cpad,
+                       scale, shift);
 }
 void launch_avgpool2_f32(hipStream_t st, const float* x, float* y, int B, int H, int W, int C) {
   hipLaunchKernelGGL(k_avgpool2_f32, dim3(ew_grid((int64_t)B * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, st, x, y, B,

@@ -260,8 +260,9 @@ void launch_groupnorm_f32(hipStream_t st, const GroupNormParams& p, void* worksp
 // softmax(scale * q k^T) v + obias on token-major fp32 tensors, head h at column h*D
 void launch_attention_f32(hipStream_t st, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                           float* o, int ldo, int B, int H, int T, int D, float scale, const float* obias);
+// split = 1: the fp16 pair form [pixel][hi(Cpad) | lo(Cpad)] of CD_PREC_F32X3 (same bytes), range guard in `overflow`
 void launch_nchw_to_nhwc_f32(hipStream_t st, const float* x, float* y, int B, int C, int HW, int Cpad, float scale,
-                             float shift);
+                             float shift, int split = 0, int* overflow = nullptr);
 void launch_avgpool2_f32(hipStream_t st, const float* x, float* y, int B, int H, int W, int C);
 void launch_upsample2_f32(hipStream_t st, const float* x, float* y, int B, int H, int W, int C);
 // Split-fp16 mode of the fp32 path (precision CD_PREC_F32X3): a GroupNorm-ed activation x is kept as the fp16 pair

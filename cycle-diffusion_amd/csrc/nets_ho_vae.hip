@@ -391,6 +391,7 @@ void UNetHo::forward(Ctx& c, const UNetIO& io) {
                     te_.proj_total, 1, 0);
   const int pl = te_.proj_total;
   Act x; x.p = (bf16_t*)io.xin; x.B = B; x.H = R; x.W = R; x.C = in_cpad; x.ld = in_cpad; x.f32 = f32;
+  if (x3) { x.split = true; x.ld = 2 * in_cpad; }  // the samplers hand CD_PREC_F32X3 networks their input as fp16 pairs
   ConvOpts o3; o3.want_stats = true;
   std::vector<Act> hs;
   hs.push_back(conv_fwd(c, *cin_, x, nullptr, o3));

@@ -562,6 +562,7 @@ void UNetOpenAI::forward(Ctx& c, const UNetIO& io) {
                     te_.proj_total, 1, 0);
   const int proj_ld = te_.proj_total;
   Act x; x.p = (bf16_t*)io.xin; x.B = B; x.H = R; x.W = R; x.C = in_cpad; x.ld = in_cpad; x.f32 = f32;
+  if (x3) { x.split = true; x.ld = 2 * in_cpad; }  // the samplers hand CD_PREC_F32X3 networks their input as fp16 pairs
   std::vector<Act> hs;
   Act h = x;
   size_t first_full = 0;  // first input block that runs at the full batch
