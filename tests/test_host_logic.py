@@ -35,6 +35,28 @@ def test_bench_config_is_the_c2_gan_section():
     assert list(k for k, _ in args.gan) == sorted(gan)  # iteration order: sorted keys
 
 
+def test_reference_ensemble_config_runs_as_written():
+    """the reference's SD experiment (config/experiments/translate_text2img256_stable_diffusion_stochastic_1.cfg): 15
+    trials x 6 skips x 6 decoder scales = 540 candidates per image; bench.py's c2e workload prices exactly that"""
+    args = get_config("experiments/translate_text2img256_stable_diffusion_stochastic_1.cfg",
+                      config_root=os.path.join(ROOT, "config"))
+    gan = dict(iter(args.gan))
+    assert gan["gan_type"] == "SDStochasticText" and gan["n_trials"] == 15 and gan["eta"] == 0.1
+    assert gan["skip_steps"] == [15, 20, 25, 30, 40, 50]
+    assert gan["decoder_unconditional_guidance_scales"] == [1, 1.5, 2, 3, 4, 5]
+    assert gan["encoder_unconditional_guidance_scales"] == [1]
+    n = gan["n_trials"] * len(gan["skip_steps"]) * len(gan["decoder_unconditional_guidance_scales"])
+    assert n == 540
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    wl = bench.WORKLOADS["c2e"]
+    steps = sum(gan["custom_steps"] - s for s in gan["skip_steps"])  # 414 sampler steps per trial and scale
+    fwd = 15 * steps * (1 + 1 + 2 * 5)  # encode at scale 1, decode at scale 1 (one forward) and at 5 CFG scales (two)
+    assert wl["flop_per_image"] == bench.F_VAE_ENC + fwd * bench.F_UNET + 540 * bench.F_VAE_DEC
+
+
 def test_get_gan_wrapper_kwarg_remapping(monkeypatch):
     seen = {}
 
