@@ -3,6 +3,7 @@
   python -m oracle.gen_golden_full --only c2      (~25 min on 8 cores)
   python -m oracle.gen_golden_full --only c3      (~6 min)
   python -m oracle.gen_golden_full --only c5r     (~8 min; BASELINE config 5 at its real size, reduced chain)
+  python -m oracle.gen_golden_full --only c5      (~30 min; the same with the reference's full 1000 / 850 / 100 chain)
 
 One (image, source-text, target-text) triplet per BASELINE configuration, run the way the reference's
 text wrapper composes it (stable_diffusion_stochastic_text_wrapper.py:169-249): VAE encode -> posterior
@@ -90,7 +91,7 @@ def gen_c3():
     run_text_triplet("c3_ldm256_e2e", LDM_UNET, 256, 1280, sample_posterior=False)
 
 
-def gen_c5r():
+def gen_c5r(name="c5r_afhq256_e2e", custom_steps=100, es_steps=85, refine_steps=10, unrefined=True):
     """BASELINE config 5 at its real size: two `i_DDPM('AFHQ')` networks (improved_ddpm/script_util.py:5-22,102-104)
     at 256 x 256, source encodes and target decodes exactly as UnsupervisedTranslation.forward composes them
     (model/unsupervised_translation.py:49-50): z = source.encode(image) (ddpm_ddim_wrapper.py:455-534), img =
@@ -107,26 +108,37 @@ def gen_c5r():
         ns, _ = load_synth(src, seeds["source"])
         nt, _ = load_synth(tgt, seeds["target"])
         assert ns == nt
-        ws = build_ref_pixel_wrapper(src, custom_steps=100, es_steps=85, eta=0.1, refine_steps=10, resolution=256)
-        wt = build_ref_pixel_wrapper(tgt, custom_steps=100, es_steps=85, eta=0.1, refine_steps=10, resolution=256)
+        ws = build_ref_pixel_wrapper(src, custom_steps=custom_steps, es_steps=es_steps, eta=0.1,
+                                     refine_steps=refine_steps, resolution=256)
+        wt = build_ref_pixel_wrapper(tgt, custom_steps=custom_steps, es_steps=es_steps, eta=0.1,
+                                     refine_steps=refine_steps, resolution=256)
         # learn_sigma stays False as the reference sets it for AFHQ (ddpm_ddim_wrapper.py:370-374): the 6-channel
         # output is split by the shape test (:236-238, :131-134) and the variance half is dropped
         img = torch.rand((1, 3, 256, 256), generator=torch.Generator().manual_seed(seeds["image"]))
         torch.manual_seed(seeds["noise"])
         with ref_import.quiet():
             z = ws.encode(image=img)
-            print("c5r encode done", time.time() - t0, flush=True)
+            print(name, "encode done", time.time() - t0, flush=True)
             out = wt(z=z)
-            print("c5r decode + refine done", time.time() - t0, flush=True)
-            wt.refine_steps = 0
-            torch.manual_seed(seeds["noise_unrefined"])
-            out0 = wt(z=z)
-        z5 = z.view(1, 85, 3, 256, 256)
-        slots = [0, 1, 42, 84]
-    save("c5r_afhq256_e2e", names=json.dumps(ns), seeds=json.dumps(seeds), custom_steps=100, es_steps=85,
-         refine_steps=10, eta=0.1, z_sub=z5[:, slots], z_sub_slots=np.asarray(slots),
+            print(name, "decode + refine done", time.time() - t0, flush=True)
+            out0 = torch.zeros(0)
+            if unrefined:
+                wt.refine_steps = 0
+                torch.manual_seed(seeds["noise_unrefined"])
+                out0 = wt(z=z)
+        z5 = z.view(1, es_steps, 3, 256, 256)
+        slots = [0, 1, es_steps // 2, es_steps - 1]
+    save(name, names=json.dumps(ns), seeds=json.dumps(seeds), custom_steps=custom_steps, es_steps=es_steps,
+         refine_steps=refine_steps, eta=0.1, z_sub=z5[:, slots], z_sub_slots=np.asarray(slots),
          z_norms=z5.flatten(2).norm(dim=2), img=out, img_unrefined=out0, cpu_seconds=time.time() - t0,
          cpu_threads=torch.get_num_threads())
+
+
+def gen_c5():
+    """BASELINE config 5 with the reference's FULL chain (translate_afhqcat256_to_afhqdog256_ddim_eta01.cfg:10-14:
+    custom_steps 1000, es_steps 850, refine_steps 100): 1000 encoder forwards on the source net, 850 + 100 on the
+    target net, batch 1. Same networks, image and seeds as the reduced fixture; no separate unrefined pass."""
+    gen_c5r("c5_afhq256_full_chain_e2e", 1000, 850, 100, unrefined=False)
 
 
 if __name__ == "__main__":
@@ -136,3 +148,5 @@ if __name__ == "__main__":
     for k, fn in dict(c3=gen_c3, c2=gen_c2, c5r=gen_c5r).items():
         if not a.only or a.only == k:
             fn()
+    if a.only == "c5":  # ~30 min: only on request
+        gen_c5()

@@ -202,13 +202,13 @@ def test_c2_fixture_triplet_folded_into_a_batch_of_32(report):
 
 
 # ---------------------------------------------------------------- BASELINE config 5 at its real size
-@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
-def test_c5_afhq_256_reduced_chain_vs_reference(report, precision):
+def _c5(report, precision, fixture, cfg):
     """Two `i_DDPM('AFHQ')` networks at 256 x 256 through the model API main.py drives
     (model/unsupervised_translation.py:27-55: z = source.encode(image); img = target(z)), sample_type 'ddim' eta 0.1,
-    REDUCED chain custom_steps 100 / es_steps 85 / refine_steps 10 (the reference cfg divided by 10), batch 1, on the
-    engine's fp32 path - against tests/golden/c5r_afhq256_e2e.npz, the reference's own DDPMDDIMWrapper pair on the same
-    weights and draws (oracle/gen_golden_full.py:gen_c5r).
+    batch 1, on the engine's fp32 path - against a fixture made by the reference's own DDPMDDIMWrapper pair on the same
+    weights and draws (oracle/gen_golden_full.py:gen_c5r / gen_c5): the REDUCED chain custom_steps 100 / es_steps 85 /
+    refine_steps 10 (the reference cfg divided by 10; c5r_afhq256_e2e.npz) or the cfg's own 1000 / 850 / 100
+    (c5_afhq256_full_chain_e2e.npz).
 
     Source and target are two DIFFERENT random-init networks, so the injected eps of one drives the other far out of
     the image range (the reference's image spans -42 ... +54; only 4 % of its pixels lie inside [0, 1]). The clamped
@@ -219,14 +219,14 @@ def test_c5_afhq_256_reduced_chain_vs_reference(report, precision):
     (include/cyclediff.h CD_PREC_F32X3) - same floor."""
     from cycle_diffusion_amd.utils.config_utils import get_config
     from cycle_diffusion_amd.utils.program_utils import get_model
-    path = os.path.join(gu.GOLD, "c5r_afhq256_e2e.npz")
+    path = os.path.join(gu.GOLD, fixture + ".npz")
     if not os.path.exists(path):
         pytest.skip("fixture not generated")
     fx = np.load(path, allow_pickle=False)
     seeds = json.loads(str(fx["seeds"]))
     os.environ["CYCLEDIFF_SYNTHETIC_WEIGHTS"] = "1"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    args = get_config("experiments/bench_afhq_c5_reduced.cfg", config_root=os.path.join(root, "config"))
+    args = get_config(cfg, config_root=os.path.join(root, "config"))
     assert (args.gan.custom_steps, args.gan.es_steps, args.gan.refine_steps) == \
         (int(fx["custom_steps"]), int(fx["es_steps"]), int(fx["refine_steps"]))
     args.gan.noise_on_cpu = True
@@ -246,13 +246,17 @@ def test_c5_afhq_256_reduced_chain_vs_reference(report, precision):
     torch.manual_seed(seeds["noise"])
     with torch.no_grad():
         (orig, img), loss, extra = model(sample_id=sid, original_image=image.cuda())
-        # the encoder's z again (same draws) for the slot-level comparison, and the unrefined decode
+        # the encoder's z again (same draws) for the slot-level comparison, and the unrefined decode where the fixture
+        # holds one
         torch.manual_seed(seeds["noise"])
         z = model.source_gan_wrapper.encode(image=image.cuda())
-        tw = model.target_gan_wrapper
-        tw.refine_steps = 0
-        torch.manual_seed(seeds["noise_unrefined"])
-        img0 = tw(z=z)
+        ref0 = torch.as_tensor(fx["img_unrefined"])
+        img0 = None
+        if ref0.numel():
+            tw = model.target_gan_wrapper
+            tw.refine_steps = 0
+            torch.manual_seed(seeds["noise_unrefined"])
+            img0 = tw(z=z)
     es = int(fx["es_steps"])
     z5 = z.view(1, es, 3, 256, 256).cpu()
     slots = [int(s) for s in fx["z_sub_slots"]]
@@ -265,12 +269,29 @@ def test_c5_afhq_256_reduced_chain_vs_reference(report, precision):
     def raw_psnr(a, b):
         return float(-10.0 * torch.log10(((a - b) ** 2).mean()))
 
-    ref, ref0 = torch.as_tensor(fx["img"]), torch.as_tensor(fx["img_unrefined"])
-    p, p0 = raw_psnr(img.cpu(), ref), raw_psnr(img0.cpu(), ref0)
-    report.add("e2e/c5r_afhq256" + ("" if precision == "fp32" else "_" + precision), raw_psnr_db=p, raw_psnr_unrefined_db=p0, clamped_psnr_db=gu.psnr(img.cpu(), ref),
+    ref = torch.as_tensor(fx["img"])
+    p = raw_psnr(img.cpu(), ref)
+    p0 = raw_psnr(img0.cpu(), ref0) if img0 is not None else None
+    report.add("e2e/" + fixture.replace("_e2e", "") + ("" if precision == "fp32" else "_" + precision), raw_psnr_db=p,
+               raw_psnr_unrefined_db=p0, clamped_psnr_db=gu.psnr(img.cpu(), ref),
                img_maxabs=(img.cpu() - ref).abs().max().item(), ref_absmax=ref.abs().max().item(),
                ref_rms=ref.pow(2).mean().sqrt().item(), xT_maxabs=xT, eps_rel_slots=eps_rel, z_norm_rel=zn_rel,
                reference_cpu_seconds=float(fx["cpu_seconds"]))
     assert orig.shape == img.shape == (1, 3, 256, 256) and float(loss.abs().sum()) == 0.0 and extra == {}
     assert xT < 1e-5 and zn_rel < 1e-4 and max(eps_rel) < 1e-2, (xT, zn_rel, eps_rel)
-    assert p >= 40.0 and p0 >= 40.0, (p, p0)
+    assert p >= 40.0 and (img0 is None or p0 >= 40.0), (p, p0)
+    return p
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
+def test_c5_afhq_256_reduced_chain_vs_reference(report, precision):
+    _c5(report, precision, "c5r_afhq256_e2e", "experiments/bench_afhq_c5_reduced.cfg")
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
+def test_c5_afhq_256_full_chain_vs_reference(report, precision):
+    """BASELINE config 5 exactly as the reference's cfg runs it (translate_afhqcat256_to_afhqdog256_ddim_eta01.cfg):
+    custom_steps 1000, es_steps 850, refine_steps 100 - 1950 U-Net forwards per image - against
+    tests/golden/c5_afhq256_full_chain_e2e.npz (oracle/gen_golden_full.py:gen_c5, the reference's own wrapper pair on the
+    CPU). Same raw-PSNR floor as the reduced chain."""
+    _c5(report, precision, "c5_afhq256_full_chain_e2e", "experiments/bench_afhq_c5.cfg")
