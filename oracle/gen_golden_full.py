@@ -3,6 +3,7 @@
   python -m oracle.gen_golden_full --only c2      (~25 min on 8 cores)
   python -m oracle.gen_golden_full --only c3      (~6 min)
   python -m oracle.gen_golden_full --only c5r     (~8 min; BASELINE config 5 at its real size, reduced chain)
+  python -m oracle.gen_golden_full --only c2ens   (~25 min; the SD wrapper's ensemble loops, SD-sized nets at 256 x 256)
   python -m oracle.gen_golden_full --only c5      (~30 min; the same with the reference's full 1000 / 850 / 100 chain)
 
 One (image, source-text, target-text) triplet per BASELINE configuration, run the way the reference's
@@ -91,6 +92,66 @@ def gen_c3():
     run_text_triplet("c3_ldm256_e2e", LDM_UNET, 256, 1280, sample_posterior=False)
 
 
+def gen_c2_ensemble():
+    """The ensemble loops of the SD wrapper (stable_diffusion_stochastic_text_wrapper.py:189-204 encode: trial -> encoder
+    scale -> skip_steps; :142-167 generate: member -> decoder scale) with the SD-v1.4-sized U-Net and the KL-f8 VAE on a
+    256 x 256 image (32 x 32 latent: the networks are fully convolutional; a quarter of the CPU time of 512 x 512):
+    n_trials 2, skip_steps [40, 50], encoder scale 1, decoder scales [1, 3] -> 4 members, 8 candidates, each produced by
+    the reference's own DDIMSampler calls with the wrapper's arguments, one member at a time. Pins skip_steps > 0, the
+    scale-1 and classifier-free-guidance decodes and the member order at the real network size; the engine folds the
+    members that share (skip, scale) into one batch."""
+    ref_import.setup()
+    from ldm.modules.distributions.distributions import DiagonalGaussianDistribution
+    Sampler = ref_import.ddim_sampler_cls()
+    res, steps, eta, wb = 256, 99, 0.1, 100
+    skips, dec_scales, n_trials = [40, 50], [1.0, 3.0], 2
+    seeds = dict(SEEDS, image=7, noise=44)
+    t0 = time.time()
+    with torch.no_grad():
+        u = build_ref_sd_unet(SD_UNET)
+        uns, _ = load_synth(u, seeds["unet"])
+        v = RefVAE(FULL_VAE)
+        vns, _ = load_synth(v, seeds["vae"])
+        shim = ref_import.LatentShim(u)
+        lat = res // 8
+        image = torch.rand((1, 3, res, res), generator=torch.Generator().manual_seed(seeds["image"]))
+        c_src, uc, c_tgt = (rnd((1, 77, 768), seeds[k]) for k in ("c_src", "uc", "c_tgt"))
+        torch.manual_seed(seeds["noise"])
+        post = DiagonalGaussianDistribution(v.moments((image - 0.5) * 2.0))
+        x0 = post.sample() * 0.18215  # one posterior draw per encode() call (:185-187)
+        z_ens = []
+        for _trial in range(n_trials):
+            for enc_scale in (1,):
+                for skip in skips:
+                    with ref_import.quiet():
+                        z_list = Sampler(shim).ddpm_ddim_encoding(steps, conditioning=c_src, batch_size=1,
+                                                                  shape=(4, lat, lat), eta=eta, white_box_steps=wb,
+                                                                  skip_steps=skip, verbose=False, x0=x0,
+                                                                  unconditional_guidance_scale=enc_scale,
+                                                                  unconditional_conditioning=uc)
+                    z_ens.append(torch.stack(z_list, dim=1))
+                    print("c2 ensemble: member", len(z_ens), "encoded", time.time() - t0, flush=True)
+        imgs, lats = [], []
+        for i, z in enumerate(z_ens):
+            skip = skips[i % len(skips)]
+            assert z.shape[1] == wb - skip
+            for sc in dec_scales:
+                with ref_import.quiet():
+                    x, _ = Sampler(shim).sample_with_eps(steps, z[:, 1:], conditioning=c_tgt, batch_size=1,
+                                                         shape=(4, lat, lat), eta=eta, verbose=False, x_T=z[:, 0],
+                                                         skip_steps=skip, unconditional_guidance_scale=sc,
+                                                         unconditional_conditioning=uc)
+                lats.append(x)
+                imgs.append((v.decode(x / 0.18215) + 1.0) / 2.0)
+                print("c2 ensemble: candidate", len(imgs), "decoded", time.time() - t0, flush=True)
+    save("c2_sd_ensemble256_e2e", unet_names=json.dumps(uns), vae_names=json.dumps(vns), seeds=json.dumps(seeds),
+         steps=steps, eta=eta, white_box_steps=wb, skip_steps=np.asarray(skips), dec_scales=np.asarray(dec_scales),
+         n_trials=n_trials, x0=x0, x_T=torch.cat([z[:, 0] for z in z_ens], 0),
+         z_norms=np.concatenate([z.flatten(2).norm(dim=2).numpy().ravel() for z in z_ens]),
+         lat=torch.cat(lats, 0), img=torch.cat(imgs, 0).to(torch.float16), cpu_seconds=time.time() - t0,
+         cpu_threads=torch.get_num_threads())
+
+
 def gen_c5r(name="c5r_afhq256_e2e", custom_steps=100, es_steps=85, refine_steps=10, unrefined=True):
     """BASELINE config 5 at its real size: two `i_DDPM('AFHQ')` networks (improved_ddpm/script_util.py:5-22,102-104)
     at 256 x 256, source encodes and target decodes exactly as UnsupervisedTranslation.forward composes them
@@ -150,3 +211,5 @@ if __name__ == "__main__":
             fn()
     if a.only == "c5":  # ~30 min: only on request
         gen_c5()
+    if a.only == "c2ens":  # ~25 min: only on request
+        gen_c2_ensemble()

@@ -124,6 +124,66 @@ def test_c3_ldm_text2img_256_end_to_end_vs_reference(report):
     _run(LatentDiffStochasticTextWrapper, "c3_ldm256_e2e", 256, 1280, report)
 
 
+# ---------------------------------------------------------------- the ensemble loops at the real network size
+def test_c2_ensemble_members_skips_and_scales_vs_reference(report):
+    """The SD wrapper's ensemble (stable_diffusion_stochastic_text_wrapper.py:142-167, 189-204) with the SD-v1.4-sized
+    U-Net and the KL-f8 VAE on a 256 x 256 image: n_trials 2 x skip_steps [40, 50] = 4 encoder runs, each decoded at
+    scales 1 (one forward per step) and 3 (classifier-free guidance) = 8 candidates. tests/golden/
+    c2_sd_ensemble256_e2e.npz holds the reference's own DDIMSampler runs, one member at a time with the wrapper's
+    arguments (oracle/gen_golden_full.py:gen_c2_ensemble); here the drop-in wrapper produces all of them through
+    encode() / generate() with the members that share (skip, scale) FOLDED into one batch of 2. Every candidate is
+    held to the 35 dB floor; member order, x_T and the latent norms are checked too."""
+    from cycle_diffusion_amd.engine import sd_v1_unet_desc
+    path = os.path.join(gu.GOLD, "c2_sd_ensemble256_e2e.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    fx = np.load(path, allow_pickle=False)
+    seeds = json.loads(str(fx["seeds"]))
+    skips, scales = [int(x) for x in fx["skip_steps"]], [float(x) for x in fx["dec_scales"]]
+    n_trials, steps, wb = int(fx["n_trials"]), int(fx["steps"]), int(fx["white_box_steps"])
+    os.environ["CYCLEDIFF_SYNTHETIC_WEIGHTS"] = "1"
+
+    class SD256(SDStochasticTextWrapper):
+        RESOLUTION = 256
+        UNET_DESC = staticmethod(lambda: sd_v1_unet_desc(32))
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        w = SD256(source_model_type="sd-v1-4.ckpt", custom_steps=steps, eta=float(fx["eta"]), white_box_steps=wb,
+                  skip_steps=skips, encoder_unconditional_guidance_scales=[1.0],
+                  decoder_unconditional_guidance_scales=scales, n_trials=n_trials,
+                  cond_stage=SeededEmbedder(768, seeds), noise_on_cpu=True,
+                  ranker=lambda img, orig, s, t: img.flatten(1).mean(1))  # ranking is not under test here
+    assert w.fold_ensemble
+    for net, key, seed in ((w.unet, "unet_names", seeds["unet"]), (w.vae, "vae_names", seeds["vae"])):
+        sd = nets.synth_state_dict(json.loads(str(fx[key])), seed)
+        n, first = w.engine.load_state_dict(net, sd)
+        assert n == 0, first
+        del sd
+    image = torch.rand((1, 3, 256, 256), generator=torch.Generator().manual_seed(seeds["image"]))
+    torch.manual_seed(seeds["noise"])  # posterior draw, then per member: randn_like(x0) + one draw per encoder step
+    with torch.no_grad():
+        z_ens = w.encode(image.cuda(), ["source"])
+        imgs = w.generate(z_ens, ["target"])
+    assert len(z_ens) == n_trials * len(skips) and len(imgs) == len(z_ens) * len(scales)
+    xT_ref, zn_ref = torch.as_tensor(fx["x_T"]), torch.as_tensor(fx["z_norms"])
+    off, xT_err, zn_rel = 0, 0.0, 0.0
+    for i, z in enumerate(z_ens):  # order: trial -> encoder scale -> skip
+        K = wb - skips[i % len(skips)]
+        z5 = z.view(1, K, 4, 32, 32).cpu()
+        xT_err = max(xT_err, (z5[:, 0] - xT_ref[i:i + 1]).abs().max().item())
+        nr = zn_ref[off:off + K]
+        zn_rel = max(zn_rel, ((z5.flatten(2).norm(dim=2)[0] - nr).abs() / nr).max().item())
+        off += K
+    assert off == zn_ref.numel()
+    ref = torch.as_tensor(fx["img"]).float()
+    ps = [gu.psnr(im.cpu(), ref[j:j + 1]) for j, im in enumerate(imgs)]  # order: member -> decoder scale
+    report.add("e2e/c2_sd_ensemble256", psnr_db_per_candidate=ps, xT_maxabs=xT_err, z_norm_rel=zn_rel,
+               reference_cpu_seconds=float(fx["cpu_seconds"]))
+    assert xT_err < 2e-3 * FMT and zn_rel < 2e-3 * FMT, (xT_err, zn_rel)
+    assert min(ps) >= PSNR_FLOOR, ps
+
+
 # ---------------------------------------------------------------- the operating point that is benchmarked: B' = 32
 class _PerSampleNoise:
     """Every sample of the batch owns a CPU generator; a draw of shape [B, ...] is the concatenation of one
