@@ -379,15 +379,15 @@ def main():
         torch.cuda.synchronize(dev)
 
     def mini_ensemble():
-        """the ensemble's engine calls at their real batch sizes but 4-step chains (skip 95) and two decoder scales:
-        warm-up (tunes the GEMM shapes of these batch sizes) and the event-instrumented roofline sample - a full ensemble
-        is ~10^2 s of GPU per image"""
-        keep = wrapper.skip_steps, wrapper.decoder_unconditional_guidance_scales
-        wrapper.skip_steps, wrapper.decoder_unconditional_guidance_scales = [95], [1, 3]
+        """the ensemble's engine calls at their real batch sizes (all decoder scales: the guided ones share launch sets)
+        but 4-step chains (skip 95): warm-up (tunes the GEMM shapes of these batch sizes) and the event-instrumented
+        roofline sample - a full ensemble is ~10^2 s of GPU per image"""
+        keep = wrapper.skip_steps
+        wrapper.skip_steps = [95]
         try:
             gather(0, compute(0, 1))
         finally:
-            wrapper.skip_steps, wrapper.decoder_unconditional_guidance_scales = keep
+            wrapper.skip_steps = keep
         torch.cuda.synchronize(dev)
 
     # warm-up: every replica runs every launch-set size once (the first one tunes unseen GEMM shapes, the others
@@ -486,8 +486,8 @@ def main():
                           "peak = 16-bit MFMA peak / 3") if x3 else "k_conv_gemm (all tile instantiations)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC, profiles/)",
-                         "operating_point": ("the ensemble's engine calls at their real batch sizes on 4-step chains (skip 95, "
-                                             "decoder scales 1 and 3), per-launch HIP events") if ensemble else
+                         "operating_point": ("the ensemble's engine calls at their real batch sizes on 4-step chains (skip 95), "
+                                             "per-launch HIP events") if ensemble else
                          "one launch set of %d steps, single stream, per-launch HIP events" % C,
                          "launches_per_step": n_launch / C, "kernel_ms_per_step": k_ms / C,
                          "algorithmic_tflop_per_step": k_flops / 1e12 / C,

@@ -553,14 +553,17 @@ int cd_dpm_encode(cd_handle h, int net, int sched_kind, const float* x0, const f
   CD_API_END
 }
 
-int cd_ddim_decode(cd_handle h, int net, int sched_kind, const float* z, int z_slots, int n_eps,
-                   const float* ctx_c, const float* ctx_uc, int ctx_len, float guidance, int B, int K,
-                   const cd_step_coef* coef_host, const float* noise_tail, uint64_t seed, float* x_out) {
-  CD_API_BEGIN
-  enter_engine(h);
+static void ddim_decode_impl(cd_handle h, int net, int sched_kind, const float* z, int z_slots, int n_eps,
+                             const float* ctx_c, const float* ctx_uc, int ctx_len, float guidance, const float* gvec,
+                             int B, int K, const cd_step_coef* coef_host, const float* noise_tail, uint64_t seed,
+                             float* x_out) {
   CD_CHECK(h && z && coef_host && x_out && B > 0 && K > 0 && n_eps <= z_slots - 1, "bad argument");
   ArenaScope arena_scope(h->arena);
   SamplerState s = setup_sampler(h, net, ctx_c, ctx_uc, ctx_len, guidance, B);
+  if (gvec) {
+    CD_CHECK(s.cfg, "per-sample guidance needs the classifier-free-guidance batch (both contexts)");
+    s.ehv.gvec = gvec;
+  }
   s.tab = upload_coef(h, coef_host, K);
   const int64_t chw = (int64_t)s.C * s.HW, n = (int64_t)B * chw;
   const int64_t zbs = (int64_t)z_slots * chw;
@@ -577,6 +580,27 @@ int cd_ddim_decode(cd_handle h, int net, int sched_kind, const float* z, int z_s
     h->pacer.tick(h->st);
   }
   HIP_CHECK(hipMemcpyAsync(x_out, s.xt, (size_t)n * 4, hipMemcpyDeviceToDevice, h->st));
+}
+
+int cd_ddim_decode(cd_handle h, int net, int sched_kind, const float* z, int z_slots, int n_eps,
+                   const float* ctx_c, const float* ctx_uc, int ctx_len, float guidance, int B, int K,
+                   const cd_step_coef* coef_host, const float* noise_tail, uint64_t seed, float* x_out) {
+  CD_API_BEGIN
+  enter_engine(h);
+  ddim_decode_impl(h, net, sched_kind, z, z_slots, n_eps, ctx_c, ctx_uc, ctx_len, guidance, nullptr, B, K, coef_host,
+                   noise_tail, seed, x_out);
+  CD_API_END
+}
+
+int cd_ddim_decode_v(cd_handle h, int net, int sched_kind, const float* z, int z_slots, int n_eps,
+                     const float* ctx_c, const float* ctx_uc, int ctx_len, const float* guidance_per_sample, int B,
+                     int K, const cd_step_coef* coef_host, const float* noise_tail, uint64_t seed, float* x_out) {
+  CD_API_BEGIN
+  enter_engine(h);
+  CD_CHECK(guidance_per_sample && ctx_c && ctx_uc, "cd_ddim_decode_v: guidance vector and both contexts are required");
+  // any scale other than 0 / 1 selects the [uncond | cond] batch (ddim.py:550-559); the vector supplies the values
+  ddim_decode_impl(h, net, sched_kind, z, z_slots, n_eps, ctx_c, ctx_uc, ctx_len, 2.0f, guidance_per_sample, B, K,
+                   coef_host, noise_tail, seed, x_out);
   CD_API_END
 }
 

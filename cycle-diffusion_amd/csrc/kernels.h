@@ -24,6 +24,8 @@ struct EpsHat {  // network output view: element (b,c,p) at p[b*sb + c*sc + p*sp
   int64_t sb, sc, sp;
   int cfg;   // 1: batch is [uncond B | cond B], combine with guidance scale g
   float g;
+  const float* gvec = nullptr;  // per-sample guidance scales [B] (device) instead of g: ensemble members that differ only
+                                // in their decoder scale share one launch set
 };
 
 void launch_init_xt(hipStream_t st, const float* x0, const float* noise, uint64_t seed,

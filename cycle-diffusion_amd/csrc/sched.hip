@@ -95,7 +95,7 @@ __device__ inline float load_eps_hat(const float* eh, int64_t sb, int64_t sc, in
 //   z[:, slot] = eps ; x_t <- x_next ; next U-Net input <- bf16(x_next)
 __global__ void k_encode_step_ddim(const float* __restrict__ x0, float* __restrict__ xt,
                                    const float* __restrict__ eh, int64_t eh_sb, int64_t eh_sc,
-                                   int64_t eh_sp, int cfg, float g,
+                                   int64_t eh_sp, int cfg, float g, const float* __restrict__ gvec,
                                    const float* __restrict__ noise, uint64_t seed,
                                    uint32_t stream, float* __restrict__ z, int64_t z_bstride,
                                    int B, int C, int HW, const StepCoef* tab, const int* step_ptr,
@@ -119,7 +119,7 @@ __global__ void k_encode_step_ddim(const float* __restrict__ x0, float* __restri
       float nn = co.sigma * nz;
       xn = co.sap * x0v + dir + nn;
     }
-    float e = load_eps_hat(eh, eh_sb, eh_sc, eh_sp, b, c, p, B, cfg, g);
+    float e = load_eps_hat(eh, eh_sb, eh_sc, eh_sp, b, c, p, B, cfg, gvec ? gvec[b] : g);
     float px0 = (xtv - co.r * e) / co.sa;
     float dir2 = co.dirc * e;
     float eps = (xn - co.sap * px0 - dir2) / co.sigma;
@@ -134,6 +134,7 @@ __global__ void k_encode_step_ddim(const float* __restrict__ x0, float* __restri
 // eps == nullptr -> fresh Gaussian noise (diffusion_utils.denoising_step; refinement loop).
 __global__ void k_decode_step_ddim(float* __restrict__ x, const float* __restrict__ eh,
                                    int64_t eh_sb, int64_t eh_sc, int64_t eh_sp, int cfg, float g,
+                                   const float* __restrict__ gvec,
                                    const float* __restrict__ eps, int64_t eps_bstride,
                                    const float* __restrict__ noise, uint64_t seed,
                                    uint32_t stream, int B, int C, int HW, const StepCoef* tab,
@@ -147,7 +148,7 @@ __global__ void k_decode_step_ddim(float* __restrict__ x, const float* __restric
     int64_t rem = i - (int64_t)b * C * HW;
     int c = (int)(rem / HW), p = (int)(rem - (int64_t)c * HW);
     float xv = x[i];
-    float e = load_eps_hat(eh, eh_sb, eh_sc, eh_sp, b, c, p, B, cfg, g);
+    float e = load_eps_hat(eh, eh_sb, eh_sc, eh_sp, b, c, p, B, cfg, gvec ? gvec[b] : g);
     float px0 = (xv - co.r * e) / co.sa;
     float dir = co.dirc * e;
     float nz;
@@ -242,7 +243,7 @@ void launch_encode_step(hipStream_t st, int kind, const float* x0, float* xt, co
   int64_t n = (int64_t)B * C * HW;
   if (kind == SCHED_DDIM) {
     hipLaunchKernelGGL(k_encode_step_ddim, dim3(ew_grid(n)), dim3(256), 0, st, x0, xt, eh.p,
-                       eh.sb, eh.sc, eh.sp, eh.cfg, eh.g, noise, seed, stream, z, z_bstride, B, C,
+                       eh.sb, eh.sc, eh.sp, eh.cfg, eh.g, eh.gvec, noise, seed, stream, z, z_bstride, B, C,
                        HW, tab, step_ptr, step, is_last, xin, xin_cpad, cfg_dup_next);
   } else {
     hipLaunchKernelGGL(k_encode_step_ddpm, dim3(ew_grid(n)), dim3(256), 0, st, x0, xt, eh.p,
@@ -258,7 +259,7 @@ void launch_decode_step(hipStream_t st, int kind, float* x, const EpsHat& eh, co
   int64_t n = (int64_t)B * C * HW;
   if (kind == SCHED_DDIM) {
     hipLaunchKernelGGL(k_decode_step_ddim, dim3(ew_grid(n)), dim3(256), 0, st, x, eh.p, eh.sb,
-                       eh.sc, eh.sp, eh.cfg, eh.g, eps, eps_bstride, noise, seed, stream, B, C, HW,
+                       eh.sc, eh.sp, eh.cfg, eh.g, eh.gvec, eps, eps_bstride, noise, seed, stream, B, C, HW,
                        tab, step_ptr, step, xin, xin_cpad, cfg_dup_next, x0_pred);
   } else {
     hipLaunchKernelGGL(k_decode_step_ddpm, dim3(ew_grid(n)), dim3(256), 0, st, x, eh.p, eh.sb,

@@ -315,7 +315,8 @@ class Engine:
 
     def ddim_decode(self, net, kind, z, coef, n_eps=None, ctx_c=None, ctx_uc=None, guidance=1.0, noise_tail=None,
                     seed=0):
-        """z [B, T, C, H, W]; coef K rows; returns x [B, C, H, W]."""
+        """z [B, T, C, H, W]; coef K rows; returns x [B, C, H, W]. `guidance`: one scale, or a sequence / tensor of B
+        scales (each neither 0 nor 1: cd_ddim_decode_v) when the samples of the batch differ in it."""
         z = self._f32(z)
         B, T, Cc, H, W = z.shape
         K = len(coef)
@@ -324,12 +325,19 @@ class Engine:
         x = torch.empty((B, Cc, H, W), device=z.device, dtype=torch.float32)
         coef = np.ascontiguousarray(coef)
         L = ctx_c.shape[1] if ctx_c is not None else (ctx_uc.shape[1] if ctx_uc is not None else 0)
-        check(self.lib.cd_ddim_decode(self.h, net, kind, ptr(z), T, n_eps,
-                                      ptr(self._f32(ctx_c)) if ctx_c is not None else None,
-                                      ptr(self._f32(ctx_uc)) if ctx_uc is not None else None,
-                                      L, C.c_float(guidance), B, K, C.c_void_p(coef.ctypes.data),
-                                      ptr(self._f32(noise_tail)) if noise_tail is not None else None,
-                                      C.c_uint64(seed), ptr(x)))
+        cc = ptr(self._f32(ctx_c)) if ctx_c is not None else None
+        cu = ptr(self._f32(ctx_uc)) if ctx_uc is not None else None
+        nt = ptr(self._f32(noise_tail)) if noise_tail is not None else None
+        if isinstance(guidance, (int, float)):
+            check(self.lib.cd_ddim_decode(self.h, net, kind, ptr(z), T, n_eps, cc, cu, L, C.c_float(guidance), B, K,
+                                          C.c_void_p(coef.ctypes.data), nt, C.c_uint64(seed), ptr(x)))
+        else:
+            g = torch.as_tensor(guidance, dtype=torch.float32).to(z.device).contiguous()
+            if g.numel() != B or bool(((g == 0) | (g == 1)).any()):
+                raise ValueError("per-sample guidance: B scales, none of them 0 or 1")
+            check(self.lib.cd_ddim_decode_v(self.h, net, kind, ptr(z), T, n_eps, cc, cu, L, ptr(g), B, K,
+                                            C.c_void_p(coef.ctypes.data), nt, C.c_uint64(seed), ptr(x)))
+            self._keep = g  # the launches read it asynchronously
         return x
 
     def pix_refine(self, net, kind, x, coef, noise=None, seed=0):

@@ -140,6 +140,14 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
             return torch.randn(shape).to(self.device)
         return torch.randn(shape, device=self.device)
 
+    @staticmethod
+    def _chunks(idx, per_call):
+        """split a group into the fewest engine calls of at most `per_call` members, as evenly as possible (75 members
+        at 32 per call -> 25 + 25 + 25 rather than 32 + 32 + 11: no small tail call, one batch shape per group)"""
+        n_calls = -(-len(idx) // per_call)
+        size = -(-len(idx) // n_calls)
+        return [idx[i:i + size] for i in range(0, len(idx), size)]
+
     def _groups(self, keys):
         """indices of ensemble members grouped by key, in first-appearance order; singletons when folding is off"""
         if not self.fold_ensemble:
@@ -186,8 +194,7 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
         per_call = max(1, self.MAX_FOLD // bsz)
         for grp in self._groups([(m[0], m[1]) for m in members]):
             enc_scale, skip = members[grp[0]][0], members[grp[0]][1]
-            for j0 in range(0, len(grp), per_call):
-                idx = grp[j0:j0 + per_call]
+            for idx in self._chunks(grp, per_call):
                 n = len(idx)
                 z = self.engine.dpm_encode(self.unet, _ffi.CD_SCHED_DDIM, x0.repeat(n, 1, 1, 1), sch.coef_encode(skip),
                                            ctx_c=c.repeat(n, 1, 1), ctx_uc=uc.repeat(n, 1, 1), guidance=enc_scale,
@@ -210,15 +217,26 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
                 jobs.append((i * n_dec + j, int(skip), float(dec_scale), zz))
         img_ensemble = [None] * len(jobs)
         per_call = max(1, self.MAX_FOLD // bsz)
-        for grp in self._groups([(jb[1], jb[2]) for jb in jobs]):
-            skip, dec_scale = jobs[grp[0]][1], jobs[grp[0]][2]
-            for j0 in range(0, len(grp), per_call):
-                idx = grp[j0:j0 + per_call]
+
+        def kind(scale):  # which network batch a scale needs (ddim.py:550-559)
+            return "cond" if scale == 1.0 else ("uncond" if scale == 0.0 else "cfg")
+
+        # jobs that share the skip and the batch structure fold into one engine call; inside a classifier-free-guidance
+        # group every sample carries its own scale (cd_ddim_decode_v), so the 5 guided scales of the reference's config
+        # fill the calls instead of running 15 members at a time
+        for grp in self._groups([(jb[1], kind(jb[2]), jb[2] if kind(jb[2]) != "cfg" else None) for jb in jobs]):
+            skip = jobs[grp[0]][1]
+            for idx in self._chunks(grp, per_call):
                 n = len(idx)
+                scales = [jobs[i][2] for i in idx]
+                if kind(scales[0]) == "cfg" and len(set(scales)) > 1:
+                    guidance = torch.tensor([sc for sc in scales for _ in range(bsz)], dtype=torch.float32)
+                else:
+                    guidance = scales[0]
                 x = self.engine.ddim_decode(self.unet, _ffi.CD_SCHED_DDIM,
                                             torch.cat([jobs[i][3] for i in idx], dim=0).contiguous(),
                                             sch.coef_decode(skip), ctx_c=c.repeat(n, 1, 1), ctx_uc=uc.repeat(n, 1, 1),
-                                            guidance=dec_scale)
+                                            guidance=guidance)
                 # decode_first_stage, then post_process (x+1)/2 fused into the final layout kernel
                 img = self.engine.vae_decode(self.vae, x, scale=self.SCALE_FACTOR, out_mul=0.5, out_add=0.5)
                 for j, i in enumerate(idx):

@@ -167,6 +167,14 @@ int cd_ddim_decode(cd_handle h, int net, int sched_kind, const float* z, int z_s
                    const float* ctx_c, const float* ctx_uc, int ctx_len, float guidance, int B, int K,
                    const cd_step_coef* coef_host, const float* noise_tail, uint64_t seed, float* x_out);
 
+/* The same with one classifier-free-guidance scale PER SAMPLE (`guidance_per_sample`: device pointer, B floats, each
+ * neither 0 nor 1): the ensemble loop of the text wrappers decodes every z at each of
+ * `decoder_unconditional_guidance_scales` (stable_diffusion_stochastic_text_wrapper.py:155-166) - members that differ
+ * only in that scale run as one batch. Per-sample arithmetic is that of cd_ddim_decode with the sample's scale. */
+int cd_ddim_decode_v(cd_handle h, int net, int sched_kind, const float* z, int z_slots, int n_eps,
+                     const float* ctx_c, const float* ctx_uc, int ctx_len, const float* guidance_per_sample, int B,
+                     int K, const cd_step_coef* coef_host, const float* noise_tail, uint64_t seed, float* x_out);
+
 /* Stochastic refinement (ddpm_ddim_wrapper.py:431-453): x_t = sa*x + s1a*n (row R of coef_host),
  * then R random-noise steps rows R-1..0. noise [R+1,B,C,H,W] or NULL. In/out x [B,C,H,W]. */
 int cd_pix_refine(cd_handle h, int net, int sched_kind, float* x, int B, int R,

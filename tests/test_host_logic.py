@@ -90,6 +90,14 @@ def test_ensemble_grouping_preserves_first_appearance_order():
     assert _LatentStochasticTextWrapper._groups(w, keys) == [[0], [1], [2], [3], [4]]
 
 
+def test_ensemble_groups_are_cut_into_even_engine_calls():
+    cut = _LatentStochasticTextWrapper._chunks
+    assert [len(c) for c in cut(list(range(75)), 32)] == [25, 25, 25]  # 5 guided scales x 15 trials of one skip
+    assert [len(c) for c in cut(list(range(15)), 32)] == [15]
+    assert [len(c) for c in cut(list(range(33)), 32)] == [17, 16]
+    assert sum(cut(list(range(75)), 32), []) == list(range(75))  # order preserved
+
+
 def test_stand_in_tokenizers_keep_the_reference_framing():
     ids = HashTokenizer()(["a photo of a cat", "", "A Photo"])
     assert ids.shape == (3, 77) and ids.dtype == torch.int32
