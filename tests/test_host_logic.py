@@ -98,6 +98,51 @@ def test_ensemble_groups_are_cut_into_even_engine_calls():
     assert sum(cut(list(range(75)), 32), []) == list(range(75))  # order preserved
 
 
+def test_generate_folds_the_reference_ensemble_into_the_expected_engine_calls():
+    """generate() on the reference's SD config (15 trials x 6 skips, 6 decoder scales) with a recording stand-in for the
+    engine: per skip one conditional-only call of 15 members (scale 1: ddim.py:550) and three guided calls of 25 members
+    carrying one scale per sample; every candidate lands in the slot of the reference's loop order (member -> scale)."""
+    from cycle_diffusion_amd import schedule
+    skips, scales, trials = [15, 20, 25, 30, 40, 50], [1, 1.5, 2, 3, 4, 5], 15
+    w = object.__new__(_LatentStochasticTextWrapper)
+    torch.nn.Module.__init__(w)
+    w.skip_steps, w.decoder_unconditional_guidance_scales, w.n_trials = skips, scales, trials
+    w.white_box_steps, w.custom_steps, w.eta, w.fold_ensemble = 100, 99, 0.1, True
+    w.channels, w.image_size = 4, 2
+    w.alphas_cumprod = schedule.latent_alphas_cumprod(1000, 0.00085, 0.0120)
+    w.cond_stage = lambda texts: torch.zeros(len(texts), 77, 8)
+    w.unet = w.vae = 0
+    w._anchor = torch.nn.Parameter(torch.zeros(1))
+    calls = []
+
+    class Eng:
+        def ddim_decode(self, net, kind, z, coef, ctx_c=None, ctx_uc=None, guidance=1.0, **kw):
+            calls.append((z.shape[0], len(coef), guidance))
+            return z[:, 0].clone()  # each member's x_T carries its tag
+
+        def vae_decode(self, net, x, **kw):
+            return x
+
+    w.engine = Eng()
+    z_ens = []
+    for i in range(trials * len(skips)):  # member i: every element = i
+        K = 100 - skips[i % len(skips)]
+        z_ens.append(torch.full((1, K * 4 * 2 * 2), float(i)))
+    imgs = w.generate(z_ens, ["target"])
+    assert len(imgs) == 540
+    for i in range(90):
+        for j in range(6):
+            assert float(imgs[i * 6 + j].flatten()[0]) == float(i)  # slot = member * n_scales + scale index
+    assert len(calls) == 6 * 4
+    for skip in skips:
+        mine = [c for c in calls if c[1] == 99 - skip]
+        assert sorted(c[0] for c in mine) == [15, 25, 25, 25]
+        cond = [c for c in mine if c[0] == 15][0]
+        assert cond[2] == 1.0
+        guided = sorted(sum((c[2].tolist() for c in mine if c[0] == 25), []))
+        assert guided == sorted([float(s) for s in scales[1:]] * trials)
+
+
 def test_stand_in_tokenizers_keep_the_reference_framing():
     ids = HashTokenizer()(["a photo of a cat", "", "A Photo"])
     assert ids.shape == (3, 77) and ids.dtype == torch.int32
