@@ -176,6 +176,25 @@ __global__ __launch_bounds__(256) void k_gn_partial_f32(const float* __restrict_
   const int b = blockIdx.y, s = blockIdx.x;
   const int ppb = (HW + S - 1) / S;
   const int p0 = s * ppb, p1 = min(HW, p0 + ppb);
+  if (C4 > 256) {  // wide concat inputs (> 1024 channels): one pixel per sweep, thread t owns channel quads t, t + 256, ...
+    for (int cv = threadIdx.x; cv < C4; cv += 256) {
+      const int c = cv * 4;
+      const bool first = c < C0;
+      const float* base = first ? x0 : x1;
+      const int ld = first ? ld0 : ld1;
+      const int cc = first ? c : c - C0;
+      double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int p = p0; p < p1; ++p) {
+        const f4 v = *(const f4*)(base + ((int64_t)b * HW + p) * ld + cc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] += (double)v[e]; a[4 + e] += (double)v[e] * (double)v[e]; }
+      }
+      double* o = part + (((int64_t)b * S + s) * C4 + cv) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = a[e];
+    }
+    return;
+  }
   const int tpp = C4;                           // threads per pixel
   const int pix_per_iter = 256 / tpp;           // whole pixels per sweep; threads beyond that idle
   const int tid = threadIdx.x;
@@ -538,7 +557,7 @@ size_t groupnorm_f32_workspace(int B, int HW, int C) {  // bytes
 }
 void launch_groupnorm_f32(hipStream_t st, const GroupNormParams& p, void* workspace) {
   const int C = p.C0 + p.C1;
-  CD_CHECK(C % 32 == 0 && C <= 1024 && p.G == 32, "groupnorm_f32: channels %d", C);
+  CD_CHECK(C % 32 == 0 && C <= 4096 && p.G == 32, "groupnorm_f32: channels %d", C);
   CD_CHECK(p.C0 % 4 == 0 && (p.ld0 % 4) == 0 && (!p.x1 || (p.ld1 % 4) == 0), "groupnorm_f32: alignment");
   const int S = groupnorm_f32_slabs(p.B, p.HW);
   double* part = (double*)workspace;

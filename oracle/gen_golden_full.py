@@ -3,6 +3,7 @@
   python -m oracle.gen_golden_full --only c2      (~25 min on 8 cores)
   python -m oracle.gen_golden_full --only c3      (~6 min)
   python -m oracle.gen_golden_full --only c5r     (~8 min; BASELINE config 5 at its real size, reduced chain)
+  python -m oracle.gen_golden_full --only ldm_uncond  (~6 min; the unconditional-LDM U-Net at full size, latent side)
   python -m oracle.gen_golden_full --only c2ens   (~25 min; the SD wrapper's ensemble loops, SD-sized nets at 256 x 256)
   python -m oracle.gen_golden_full --only c5      (~30 min; the same with the reference's full 1000 / 850 / 100 chain)
 
@@ -152,6 +153,42 @@ def gen_c2_ensemble():
          cpu_threads=torch.get_num_threads())
 
 
+LDM_UNCOND_UNET = dict(image_size=64, in_channels=3, out_channels=3, model_channels=224, attention_resolutions=[8, 4, 2],
+                       num_res_blocks=2, channel_mult=[1, 2, 3, 4], num_head_channels=32)  # celeba256 / ffhq256 config.yaml:17-34
+
+
+def gen_ldm_uncond_full():
+    """gan_type LatentDiffStochastic at the real network size, latent side: the celeba256 / ffhq256 U-Net (224 channels,
+    AttentionBlocks with the legacy QKV order) on a 3 x 64 x 64 latent through the reference's DDIMSampler -
+    ddpm_ddim_encoding, sample_with_eps and refine (ddim.py:114-168, 339-393; eta 1) - with the chain of the reference
+    cfg (999 / 1000 / 400) divided by ~10: 99 steps, white_box_steps 100, refine_steps 40. The VQ first stage is left out
+    (its codebook lookup lives in taming-transformers, absent here): x0 is a seeded latent, outputs are latents."""
+    Sampler = ref_import.ddim_sampler_cls()
+    S, R = 99, 40
+    t0 = time.time()
+    with torch.no_grad():
+        u = build_ref_sd_unet(LDM_UNCOND_UNET)
+        uns, _ = load_synth(u, 308)
+        shim = ref_import.LatentShim(u, linear_start=0.0015, linear_end=0.0195)
+        x0 = rnd((1, 3, 64, 64), 313)
+        torch.manual_seed(7171)
+        with ref_import.quiet():
+            z_list = Sampler(shim).ddpm_ddim_encoding(S, batch_size=1, shape=(3, 64, 64), eta=0.1, white_box_steps=S + 1,
+                                                      verbose=False, x0=x0)
+            z = torch.stack(z_list, dim=1)
+            print("ldm_uncond_full: encode done", time.time() - t0, flush=True)
+            x_dec, _ = Sampler(shim).sample_with_eps(S, z[:, 1:], batch_size=1, shape=(3, 64, 64), eta=0.1,
+                                                     verbose=False, x_T=z[:, 0])
+        torch.manual_seed(8282)
+        with ref_import.quiet():
+            x_ref, _ = Sampler(shim).refine(S, refine_steps=R, batch_size=1, shape=(3, 64, 64), eta=1, verbose=False,
+                                            x0=x_dec)
+        slots = [0, 1, 50, 99]
+    save("ldm_uncond_full_latent", unet_names=json.dumps(uns), useed=308, x0_seed=313, noise_seed=7171, refine_seed=8282,
+         steps=S, refine_steps=R, x0=x0, z_sub=z[:, slots], z_sub_slots=np.asarray(slots),
+         z_norms=z.flatten(2).norm(dim=2), x_dec=x_dec, x_ref=x_ref, cpu_seconds=time.time() - t0)
+
+
 def gen_c5r(name="c5r_afhq256_e2e", custom_steps=100, es_steps=85, refine_steps=10, unrefined=True):
     """BASELINE config 5 at its real size: two `i_DDPM('AFHQ')` networks (improved_ddpm/script_util.py:5-22,102-104)
     at 256 x 256, source encodes and target decodes exactly as UnsupervisedTranslation.forward composes them
@@ -213,3 +250,5 @@ if __name__ == "__main__":
         gen_c5()
     if a.only == "c2ens":  # ~25 min: only on request
         gen_c2_ensemble()
+    if a.only == "ldm_uncond":  # ~6 min
+        gen_ldm_uncond_full()

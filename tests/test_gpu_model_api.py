@@ -64,13 +64,14 @@ def test_unconditional_ldm_translation_config_at_full_size(tmp_path):
     translate_ffhq256_to_celeba256_latentdiff_ddim_eta01.cfg): gan_type LatentDiffStochastic, two full-size
     unconditional LDMs (224-channel U-Net on 64 x 64 latents, VQ-f4 first stage with its 8192-row codebook),
     custom_steps 999, white_box_steps 1000, eta 0.1, refine_steps 400 - 2398 U-Net forwards for one 256 x 256 image,
-    through get_config -> get_model -> forward. Seeded synthetic weights (no checkpoints in this tree): what is checked
+    through get_config -> get_model -> forward, with `precision = fp32x3` (this repo's key: the U-Nets on the split mode of
+    the fp32 path, which is what follows the reference on eta-0.1 chains of this length). Seeded synthetic weights (no checkpoints in this tree): what is checked
     is that the whole configuration runs at its real size and returns a finite image of the right shape; parity of this
     wrapper is pinned on the small networks of test_gpu_ldm_uncond.py."""
     cfg = tmp_path / "ffhq_to_celeba.cfg"
     cfg.write_text("[model]\nname = unsupervised_translation\n\n[gan]\ngan_type = LatentDiffStochastic\n"
                    "source_model_type = ffhq256\ntarget_model_type = celeba256\ncustom_steps = 999\n"
-                   "white_box_steps = 1000\neta = 0.1\nrefine_steps = 400\n")
+                   "white_box_steps = 1000\neta = 0.1\nrefine_steps = 400\nprecision = fp32x3\n")
     os.environ["CYCLEDIFF_SYNTHETIC_WEIGHTS"] = "1"
     args = get_config(str(cfg))
     with warnings.catch_warnings():
@@ -79,6 +80,7 @@ def test_unconditional_ldm_translation_config_at_full_size(tmp_path):
     src, tgt = model.source_gan_wrapper, model.target_gan_wrapper
     assert src.resolution == tgt.resolution == 256 and src.latent_dim == 64 * 64 * 3 * 1000
     assert (src.custom_steps, src.white_box_steps, tgt.refine_steps) == (999, 1000, 400)
+    assert src.precision == tgt.precision == "fp32x3"
     img = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(3)).cuda()
     with torch.no_grad():
         (orig, out), loss, extra = model(sample_id=torch.zeros(1, dtype=torch.int64).cuda(), original_image=img)
