@@ -4,7 +4,12 @@
 metric; SURVEY.md §8d "C2 headline"), synthetic weights / images / contexts (no checkpoints here).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL for the output gather)
+  (N > 1: one rank per GPU, RCCL for the output gather. Either the caller starts the ranks - `python -m
+  torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`,
+  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env - or the plain command is given and bench.py starts them
+  itself: with --gpus N > 1 and no WORLD_SIZE in the environment it re-executes under torch.distributed.run on
+  127.0.0.1 with a free port and relays rank 0's JSON line; the reference's ranks are started the same way,
+  README.md:153 `python -m torch.distributed.launch --nproc_per_node 8 ... main.py`, trainer/trainer.py:174-179.)
 
 A "step" = one pass of the hot path over one batch of 4 image triplets per GPU: the model API
 forward = wrapper.encode (VAE encode + DPM-Encoder) + wrapper.forward (coupled decode + VAE decode),
@@ -28,6 +33,8 @@ image, ~93 s per image: use --steps 1 --warmup 0).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -243,6 +250,94 @@ def pmc_traffic_per_launch():
     return None
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` given as ONE command (no WORLD_SIZE in the environment): start the N ranks under
+    torch.distributed.run on this node - rendezvous on 127.0.0.1 (the container hostname may not resolve), a free
+    port, dmabuf IPC for RCCL - and hand back its exit code; rank 0's JSON line goes to this process's stdout."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n_ranks)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
+def dry_main(a, wl, rank, world):
+    """--dry-run: the host side of a run - rank set-up, contiguous sharding, launch sets, the per-step all-gather in
+    step order, barrier-bracketed timing, MAX over ranks, ONE JSON line from rank 0 - with a stand-in for the engine
+    call (CPU tensors, gloo instead of RCCL). What the CPU tests drive at world size 2; it measures nothing."""
+    from cycle_diffusion_amd.parallel import gather_outputs, run_in_flight, shard_range
+    if world > 1 or a.force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, R = a.batch or wl["batch"], 8
+    C = a.coalesce if a.coalesce > 0 else wl.get("coalesce", 4)
+    lo, hi = shard_range(B * world, world, rank)
+    g = torch.Generator().manual_seed(1)
+    images = torch.rand(C, B * world, 3, R, R, generator=g)[:, lo:hi]
+    sets = [C] * (a.steps // C) + ([a.steps % C] if a.steps % C else [])
+
+    def compute(_r, i):
+        n = sets[i] if i < len(sets) else C
+        time.sleep(0.001)
+        im = images[:n].reshape(n * (hi - lo), 3, R, R)
+        return (im, 1.0 - im), torch.zeros(n * (hi - lo)), {}
+
+    seen = []
+
+    def gather(_r, res):
+        (orig, img), loss, _ = res
+        out = None
+        for i in range(img.shape[0] // B):
+            sl = slice(i * B, (i + 1) * B)
+            out = gather_outputs((orig[sl], img[sl]), loss[sl])
+            seen.append(out[0][1].shape[0])
+        return out
+
+    def sync():
+        if dist.is_initialized():
+            dist.barrier()
+
+    done = 0
+    while done < a.warmup:
+        gather(0, compute(0, len(sets)))
+        done += C
+    del seen[:]
+    sync()
+    t0 = time.perf_counter()
+    out = run_in_flight(len(sets), 1, compute, gather, pass_index=True)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist.is_initialized():
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    res = None
+    if rank == 0:
+        assert len(seen) == a.steps and all(n == B * world for n in seen), seen  # one full global batch per step
+        assert torch.equal(out[0][1], 1.0 - out[0][0])
+        res = {"metric": wl["metric"], "value": a.steps * B * world / dt, "unit": "images/s", "n_gpus": world,
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry run: no engine call, host plumbing only",
+               "dry_run": True,
+               "config": {"workload": wl["name"], "batch_per_gpu": B, "global_batch": B * world,
+                          "parallelism": "dp%d" % world, "steps_per_launch_set": C,
+                          "distributed": "gloo process group" if dist.is_initialized() else "single process"}}
+        print(json.dumps(res), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,16 +365,28 @@ def main():
                     "reference's loop) instead of folding the members that share (skip, scale) into one batch")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even at world size 1 (exercises the gather path on a 1-GPU box)")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="start the ranks under torch.distributed.run even at --gpus 1 (what --gpus N > 1 does on its own "
+                         "when WORLD_SIZE is unset): the self-launch path on a 1-GPU box; implies --force-dist")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="host plumbing only (ranks, sharding, gathers, timing, the JSON line) over gloo on CPU tensors, "
+                         "no engine call: the CPU tests of the N > 1 launch path")
     a = ap.parse_args()
     wl = WORKLOADS[a.workload]
 
+    if (a.gpus > 1 or a.self_launch) and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
+    a.force_dist = a.force_dist or a.self_launch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.dry_run:
+        assert world == a.gpus, "WORLD_SIZE %d does not match --gpus %d" % (world, a.gpus)
+        return dry_main(a, wl, rank, world)
     # host-side weight synthesis / oracle: stay inside the CPU quota, shared by the ranks of the node
     torch.set_num_threads(max(1, host_cores() // max(1, world)))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 or world > 1 or a.force_dist:
-        assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+        assert world == a.gpus, "WORLD_SIZE %d does not match --gpus %d" % (world, a.gpus)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)

@@ -536,6 +536,9 @@ int cd_dpm_encode(cd_handle h, int net, int sched_kind, const float* x0, const f
   CD_CHECK(h && x0 && coef_host && z_out && B > 0 && K > 0, "bad argument");
   ArenaScope arena_scope(h->arena);
   SamplerState s = setup_sampler(h, net, ctx_c, ctx_uc, ctx_len, guidance, B);
+  // the 'ddpm' posterior kernels carry no classifier-free-guidance combine (the pixel DDPMs that use them are unconditional,
+  // ddpm_ddim_wrapper.py:230-238): a guided call would silently run unguided
+  CD_CHECK(sched_kind == CD_SCHED_DDIM || !s.cfg, "classifier-free guidance is only implemented for sched_kind = CD_SCHED_DDIM");
   s.tab = upload_coef(h, coef_host, K + 1);
   const int64_t chw = (int64_t)s.C * s.HW, n = (int64_t)B * chw;
   const int64_t zbs = (int64_t)(K + 1) * chw;
@@ -560,6 +563,9 @@ static void ddim_decode_impl(cd_handle h, int net, int sched_kind, const float* 
   CD_CHECK(h && z && coef_host && x_out && B > 0 && K > 0 && n_eps <= z_slots - 1, "bad argument");
   ArenaScope arena_scope(h->arena);
   SamplerState s = setup_sampler(h, net, ctx_c, ctx_uc, ctx_len, guidance, B);
+  // the 'ddpm' posterior kernels carry no classifier-free-guidance combine (the pixel DDPMs that use them are unconditional,
+  // ddpm_ddim_wrapper.py:230-238): a guided call would silently run unguided
+  CD_CHECK(sched_kind == CD_SCHED_DDIM || !s.cfg, "classifier-free guidance is only implemented for sched_kind = CD_SCHED_DDIM");
   if (gvec) {
     CD_CHECK(s.cfg, "per-sample guidance needs the classifier-free-guidance batch (both contexts)");
     s.ehv.gvec = gvec;

@@ -37,7 +37,7 @@ class LatentDiffStochasticWrapper(torch.nn.Module):
 
     def __init__(self, source_model_type, custom_steps, eta, white_box_steps, refine_steps=0,
                  enforce_class_input=None, unconditional_guidance_scale=None, device=None, noise_on_cpu=False,
-                 unet_desc=None, vae_desc=None, state_dict=None, precision="fp16"):
+                 unet_desc=None, vae_desc=None, state_dict=None, precision="fp32x3", allow_lossy_16bit=False):
         super().__init__()
         if enforce_class_input:
             raise NotImplementedError("class-conditional LDMs (cin256) are not used by the reference configs")
@@ -50,18 +50,25 @@ class LatentDiffStochasticWrapper(torch.nn.Module):
         if source_model_type not in MODEL_TYPES:
             raise NotImplementedError(source_model_type)
         udesc_fn, vdesc_fn, ls, le, self.scale_factor, self.use_ema = MODEL_TYPES[source_model_type]
-        self.engine = get_engine(device)
-        # precision of the U-Net (the VQ first stage is 16-bit either way): 'fp16' (default), or the fp32 path / its split
-        # mode. These LDMs are sampled with eta 0.1 over up to 999 steps: the nearly deterministic decode amplifies the
-        # 16-bit round-off of eps_hat (full-size fixture, 99 steps: 25 dB against the reference's latent; 'fp32' 73 dB,
-        # 'fp32x3' 76 dB - tests/test_gpu_ldm_uncond.py), so `precision = fp32x3` is the setting that follows the
-        # reference on the long chains of its configs
+        # precision of the U-Net (the VQ first stage is 16-bit either way): 'fp32x3' (default: the fp32 network with its
+        # GroupNorm-fed convolutions as split-fp16 products), 'fp32' (the reference's own arithmetic), or 'fp16'. These
+        # LDMs are sampled with eta 0.1 over up to 999 steps: the nearly deterministic decode amplifies the 16-bit
+        # round-off of eps_hat (full-size fixture, 99 steps: 25 dB against the reference's latent; 'fp32' 73 dB, 'fp32x3'
+        # 76 dB - tests/test_gpu_ldm_uncond.py). The 16-bit engine is therefore refused unless asked for by name AND
+        # acknowledged (`allow_lossy_16bit`), as DDPMDDIMWrapper refuses 16-bit 'ddim' chains (allow_lossy_ddim).
         if str(precision) not in LDM_PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(LDM_PRECISIONS))
         self.precision = str(precision)
         udesc = unet_desc if unet_desc is not None else udesc_fn()
         if unet_desc is None:
             udesc.precision = LDM_PRECISIONS[self.precision]
+        else:  # an explicit descriptor carries its own precision
+            self.precision = {v: k for k, v in LDM_PRECISIONS.items() if k != "16"}[int(udesc.precision)]
+        if unet_desc is None and LDM_PRECISIONS[self.precision] == _ffi.CD_PREC_16 and not allow_lossy_16bit:
+            raise ValueError("precision=%r does not reproduce the reference on the eta-0.1 chains of the unconditional LDMs "
+                             "(about 25 dB latent signal-to-error after 99 steps against 73-76 dB); use 'fp32x3' (default) "
+                             "or 'fp32', or pass allow_lossy_16bit=True" % self.precision)
+        self.engine = get_engine(device)
         vdesc = vae_desc if vae_desc is not None else vdesc_fn()
         self.channels, self.image_size = udesc.in_channels, udesc.image_size
         self.unet = self.engine.create_net(udesc)

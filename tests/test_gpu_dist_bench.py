@@ -34,3 +34,17 @@ def test_bench_under_torchrun_world1_rccl():
     assert res["n_gpus"] == 1 and res["steps"] == 1 and res["value"] > 0
     assert res["config"]["parallelism"] == "dp1" and res["config"]["distributed"] == "nccl(RCCL) process group"
     assert 0 < res["roofline"]["frac"] < 1
+
+
+def test_bench_self_launch_as_one_command_rccl():
+    """`python bench.py --gpus N` as ONE command: no torchrun around it, no WORLD_SIZE - bench.py starts the ranks
+    itself (N = 1 here through --self-launch; N > 1 takes the same branch on its own) and relays rank 0's line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--self-launch", "--steps", "1", "--warmup", "1",
+           "--coalesce", "1", "--no-cpu-baseline", "--no-single-batch"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 1 and res["value"] > 0
+    assert res["config"]["distributed"] == "nccl(RCCL) process group"

@@ -171,6 +171,24 @@ def _c1(engine, report, fx_name, steps, eta, sample_type, precision=_ffi.CD_PREC
     return p_ref, p_img
 
 
+def test_guided_call_with_the_ddpm_posterior_form_is_refused(engine):
+    """The 'ddpm' posterior step kernels have no classifier-free-guidance combine (the pixel DDPMs are unconditional,
+    ddpm_ddim_wrapper.py:230-238): a guided call - one scale or one per sample - must raise, not run unguided."""
+    fx = gu.load("latent_cycle_tiny")
+    net, _sd = _load(engine, tiny_sd_desc(), fx)
+    x0, c, uc, _c2 = gu.latent_cycle_inputs()
+    sch = schedule.DDIMSchedule(schedule.latent_alphas_cumprod(), 4, 0.1)
+    z = torch.zeros((2, 5, 4, 16, 16)).cuda()
+    for g in (3.0, [2.0, 3.0]):
+        with pytest.raises(RuntimeError, match="CD_SCHED_DDIM"):
+            engine.ddim_decode(net, _ffi.CD_SCHED_DDPM, z, sch.coef_decode(), ctx_c=c.cuda(), ctx_uc=uc.cuda(), guidance=g)
+    with pytest.raises(RuntimeError, match="CD_SCHED_DDIM"):
+        engine.dpm_encode(net, _ffi.CD_SCHED_DDPM, x0.cuda(), sch.coef_encode(), ctx_c=c.cuda(), ctx_uc=uc.cuda(),
+                          guidance=3.0)
+    x = engine.ddim_decode(net, _ffi.CD_SCHED_DDIM, z, sch.coef_decode(), ctx_c=c.cuda(), ctx_uc=uc.cuda(), guidance=[2.0, 3.0])
+    assert torch.isfinite(x).all()  # the engine is usable after the refusals
+
+
 def test_c1_toy_ddpm_ddim_eta_fp32(engine, report):
     """BASELINE config 1 ('ddim', eta 0.1, 50 + 50 steps) on the engine's fp32 path vs the reference's CPU run:
     image PSNR >= 40 dB against the reference image (whose own PSNR against the input is 48 dB), and the result is

@@ -195,3 +195,17 @@ def test_16_bit_ddim_is_refused_by_name():
     with pytest.raises(ValueError, match="precision must be"):
         DDPMDDIMWrapper(source_model_type="toy32", sample_type="ddim", eta=0.1, custom_steps=4, es_steps=4,
                         precision="fp8")
+
+
+def test_unconditional_ldm_wrapper_refuses_the_lossy_16bit_engine_by_default():
+    """The celeba256 / ffhq256 configs sample with eta 0.1 over up to 999 steps: the 16-bit engine ends a 99-step chain
+    at 25 dB against the reference's latent (73-76 dB on the fp32 path / split mode), so - like DDPMDDIMWrapper's
+    16-bit 'ddim' - it must be asked for by name and acknowledged; the default is the split mode. Checked before any
+    engine is created (no GPU needed)."""
+    import inspect
+    from cycle_diffusion_amd.gan_wrapper.latent_wrapper import LatentDiffStochasticWrapper
+    assert inspect.signature(LatentDiffStochasticWrapper.__init__).parameters["precision"].default == "fp32x3"
+    with pytest.raises(ValueError, match="allow_lossy_16bit"):
+        LatentDiffStochasticWrapper("celeba256", custom_steps=99, eta=0.1, white_box_steps=100, precision="fp16")
+    with pytest.raises(ValueError, match="precision must be one of"):
+        LatentDiffStochasticWrapper("celeba256", custom_steps=99, eta=0.1, white_box_steps=100, precision="tf32")
