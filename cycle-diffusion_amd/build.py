@@ -42,6 +42,10 @@ def build(force=False, verbose=False, variant=None):
         objdir = os.path.join(HERE, "build", "bf16")
         lib = os.path.join(LIBDIR, "libcyclediff_bf16.so")
         defines = ["-DCD_ACT_FP16=0"]
+    elif variant == "probe":  # phase-timing instrumentation of k_conv_gemm (scripts/probe_report.py); never the product
+        objdir = os.path.join(HERE, "build", "probe")
+        lib = os.path.join(LIBDIR, "libcyclediff_probe.so")
+        defines = ["-DCD_PROBE"]
     elif variant is not None:
         raise ValueError("unknown build variant %r" % (variant,))
     os.makedirs(LIBDIR, exist_ok=True)
@@ -78,4 +82,4 @@ def build(force=False, verbose=False, variant=None):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, variant="bf16" if "--bf16" in sys.argv else None))
+    print(build(force="--force" in sys.argv, verbose=True, variant="bf16" if "--bf16" in sys.argv else ("probe" if "--probe" in sys.argv else None)))

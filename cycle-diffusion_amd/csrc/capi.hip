@@ -932,6 +932,13 @@ extern "C" int cd_op_bench_conv(cd_handle h, int B, int H, int W, int C0, int C1
     if (inplace_resid) o.resid = &ro;
     if (want_stats) o.out_stats = ro.stats_buf;
   }
+  const char* probe_path = getenv("CYCLEDIFF_PROBE_OUT");
+  const size_t probe_words = (size_t)8192 * 8 * kProbeWords;  // up to 8192 workgroups of 8 waves
+  unsigned long long* probe_buf = nullptr;
+  if (probe_path) {
+    probe_buf = (unsigned long long*)h->arena.alloc(probe_words * 8);
+    HIP_CHECK(hipMemsetAsync(probe_buf, 0, probe_words * 8, h->st));
+  }
   const size_t mk2 = h->arena.mark();
   conv_fwd(c, w, a0, C1 ? &a1 : nullptr, o);  // warm-up
   hipEvent_t e0, e1;
@@ -944,6 +951,29 @@ extern "C" int cd_op_bench_conv(cd_handle h, int B, int H, int W, int C0, int C1
   HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
   *ms_out = ms / iters;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  // phase-timing build (lib/libcyclediff_probe.so): one more launch whose waves leave their s_memtime stamps, dumped as
+  // text header + raw 64-bit words to $CYCLEDIFF_PROBE_OUT (scripts/probe_report.py reads it)
+  if (probe_buf) {
+    const char* path = probe_path;
+    const size_t words = probe_words;
+    unsigned long long* buf = probe_buf;
+    g_conv_probe = buf;
+    h->arena.release(mk2);
+    conv_fwd(c, w, a0, C1 ? &a1 : nullptr, o);
+    g_conv_probe = nullptr;
+    std::vector<unsigned long long> host(words);
+    HIP_CHECK(hipMemcpyAsync(host.data(), buf, words * 8, hipMemcpyDeviceToHost, h->st));
+    HIP_CHECK(hipStreamSynchronize(h->st));
+    if (FILE* f = fopen(path, "wb")) {
+      fprintf(f, "probe words=%d cfg=\"%s\" B=%d H=%d C0=%d C1=%d N=%d k=%d act=%d ms=%.4f\n", kProbeWords,
+              conv_gemm_last_config(), B, H, C0, C1, N, k, act, ms / iters);
+      size_t used = words;
+      while (used > 0 && host[used - 1] == 0) --used;
+      used = (used + kProbeWords - 1) / kProbeWords * kProbeWords;
+      fwrite(host.data(), 8, used, f);
+      fclose(f);
+    }
+  }
   CD_API_END
 }
 

@@ -74,6 +74,19 @@ __device__ __forceinline__ void wait_vmcnt_barrier() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+#ifdef CD_PROBE
+// Phase-timing instrumentation (probe build only): s_memtime stamps kept in SGPRs, sums formed on the scalar unit; the
+// stamp sits where no LDS read is outstanding (top / bottom of a K step), so its lgkmcnt(0) costs nothing extra.
+__device__ __forceinline__ unsigned long long probe_time() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define CD_PROBE_ONLY(...) __VA_ARGS__
+#else
+#define CD_PROBE_ONLY(...)
+#endif
+
 template <int BM, int BN, int BK, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins below: the host pass only needs the launch stub
@@ -86,6 +99,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  CD_PROBE_ONLY(
+  unsigned long long pr_t0 = probe_time(), pr_prol = 0, pr_first = 0, pr_wait = 0, pr_comp = 0, pr_maxw = 0, pr_loop = 0,
+                     pr_drain = 0, pr_stage = 0, pr_rows = 0, pr_issued = 0, pr_last = 0;
+  unsigned* pr_log = (unsigned*)(smem + T::LDS_BYTES) + wave * 64;  // (arrive, pass) of the first 32 K steps
+  if (lane < 64) pr_log[lane] = 0;)
 
   // ---- block -> tile, XCD-aware (block b runs on XCD b%8; give each XCD a contiguous tile range
   // so neighbouring n-tiles of one m-tile share the A panel in that XCD's L2)
@@ -253,9 +271,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
 
   int cur = 0;             // ring slot of tile kt
   int nxt = NSTAGE - 1;    // ring slot the next prefetch goes to (= slot of tile kt-1)
+  CD_PROBE_ONLY(pr_prol = probe_time(); pr_last = pr_prol;)
   for (int kt = kt0; kt < kt1; ++kt) {
+    CD_PROBE_ONLY(const unsigned long long pr_arr = probe_time();)
     // tile kt has landed when at most (NSTAGE-2) younger tiles (LPT loads each) are still in flight
     wait_vmcnt_barrier<(NSTAGE - 2) * LPT>();
+    CD_PROBE_ONLY({
+      const unsigned long long now = probe_time();
+      if (kt == kt0) pr_first = now;
+      else { pr_comp += pr_arr - pr_last; pr_wait += now - pr_arr; if (now - pr_arr > pr_maxw) pr_maxw = now - pr_arr; }
+      if (kt - kt0 < 32 && lane == 0) { pr_log[2 * (kt - kt0)] = (unsigned)(pr_arr - pr_t0); pr_log[2 * (kt - kt0) + 1] = (unsigned)(now - pr_t0); }
+      pr_last = now;
+    })
     // every wave has passed the barrier => everyone finished reading slot `nxt` (tile kt-1): refill it
     prepare(kt + NSTAGE - 1);
     const char* Ab = As + cur * T::A_BYTES;
@@ -305,8 +332,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
     nxt = cur;
     cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
   }
+  CD_PROBE_ONLY(pr_loop = probe_time(); pr_comp += pr_loop - pr_last;)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy tail loads before LDS is reused
   __syncthreads();  // all waves done with the ring before the epilogue reuses LDS
+  CD_PROBE_ONLY(pr_drain = probe_time();)
 
   // ---- split-K fix-up: every split stores its fp32 partial tile (register layout, coalesced), the last
   // one to arrive sums all partials in split order (so the result does not depend on arrival order) and
@@ -374,6 +403,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
   for (int jc = 0; jc < NT; jc += CJ) {
     const int cj = (NT - jc) < CJ ? (NT - jc) : CJ;  // blocks in this chunk (compile-time after unrolling)
     const int cw = cj * 32;
+    CD_PROBE_ONLY(const unsigned long long pr_c0 = probe_time();)
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -387,6 +417,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
           }
         }
     __builtin_amdgcn_wave_barrier();
+    CD_PROBE_ONLY(const unsigned long long pr_c1 = probe_time(); pr_stage += pr_c1 - pr_c0;)
     // GEGLU: packed columns come in blocks of 64 = [32 value | 32 gate] (k_pack_rows) = one chunk; only the value
     // half produces output, at column (n/64)*32 + n%32.
     const int vpr = geglu ? 4 : (cw / 8);  // 8-wide vectors per row handled
@@ -513,7 +544,25 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
         for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
       }
     }
+    CD_PROBE_ONLY(pr_rows += probe_time() - pr_c1;)
   }
+  CD_PROBE_ONLY({
+    pr_issued = probe_time();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long pr_done = probe_time();
+    if (p.probe) {
+      unsigned hwid, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned long long* o = p.probe + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * NW + wave) * kProbeWords;
+      if (lane == 0) {
+        o[0] = pr_t0; o[1] = pr_prol; o[2] = pr_first; o[3] = pr_wait; o[4] = pr_comp; o[5] = pr_maxw; o[6] = pr_loop;
+        o[7] = pr_drain; o[8] = pr_stage; o[9] = pr_rows; o[10] = pr_issued; o[11] = pr_done; o[12] = kt1 - kt0;
+        o[13] = ((unsigned long long)xcc << 32) | hwid; o[14] = tile; o[15] = 0;
+      }
+      ((unsigned*)(o + 16))[lane] = pr_log[lane];  // the log lies beyond the tile's LDS: the epilogue did not touch it
+    }
+  })
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -523,11 +572,15 @@ int launch_cfg(hipStream_t st, const ConvGemmParams& p) {
   using T = TileCfg<BM, BN, BK, WM, WN, NSTAGE>;
   const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
   const int split = p.splitk > 1 ? p.splitk : 1;
+#ifdef CD_PROBE
+  constexpr int kLds = T::LDS_BYTES + T::NW * 256;  // + the per-wave stamp log
+#else
+  constexpr int kLds = T::LDS_BYTES;
+#endif
   static std::once_flag attr_once;  // engines on several host threads launch the same instantiation
   auto kern = k_conv_gemm<BM, BN, BK, WM, WN, NSTAGE>;
   std::call_once(attr_once, [&]() {
-    HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  T::LDS_BYTES));
+    HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
   });
   if (split > 1) {
     const SplitKWorkspace& ws = g_conv_splitk;
@@ -535,7 +588,7 @@ int launch_cfg(hipStream_t st, const ConvGemmParams& p) {
     CD_CHECK((size_t)tiles * p.nbatch * split * BM * BN * 4 <= ws.scratch_bytes && tiles * p.nbatch <= ws.nflags,
              "conv_gemm: split-K workspace too small");
   }
-  hipLaunchKernelGGL(kern, dim3(tiles, split, p.nbatch), dim3(64 * T::NW), T::LDS_BYTES, st, p);
+  hipLaunchKernelGGL(kern, dim3(tiles, split, p.nbatch), dim3(64 * T::NW), kLds, st, p);
   return 0;
 }
 
@@ -573,6 +626,7 @@ constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 }  // namespace gemm_detail
 thread_local SplitKWorkspace g_conv_splitk;
+thread_local unsigned long long* g_conv_probe = nullptr;
 namespace gemm_detail {
 
 template <int BK>
@@ -847,6 +901,7 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   if ((id >> 8) > 1) pk.splitk = id >> 8;  // from the tuner, or packed into an explicit `tile` (tests, sweeps)
   id &= 0xff;
   if (pk.splitk > 1 && !pk.sk_scratch) { pk.sk_scratch = g_conv_splitk.scratch; pk.sk_flags = g_conv_splitk.flags; }
+  pk.probe = g_conv_probe;
   static const CfgInfo kLinStreamCfg = {kLinStreamTile, 256, 64, 64, "lin_stream 256 x N, K = 320"};
   const CfgInfo* ci = nullptr;
   if (id == kLinStreamTile) {

@@ -92,7 +92,12 @@ struct ConvGemmParams {
   int splitk = 0;
   float* sk_scratch = nullptr;    // defaults to g_conv_splitk when splitk > 1
   int* sk_flags = nullptr;
+  // phase-timing build only (-DCD_PROBE, lib/libcyclediff_probe.so; scripts/probe_report.py): every wave leaves
+  // kProbeWords 64-bit words of s_memtime stamps here, [block][wave][kProbeWords]; null = off
+  unsigned long long* probe = nullptr;
 };
+constexpr int kProbeWords = 48;
+extern thread_local unsigned long long* g_conv_probe;  // picked up by launch_conv_gemm in the probe build
 struct SplitKWorkspace {
   float* scratch = nullptr;
   size_t scratch_bytes = 0;

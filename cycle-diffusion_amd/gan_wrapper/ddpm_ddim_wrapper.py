@@ -66,6 +66,7 @@ class DDPMDDIMWrapper(torch.nn.Module):
                              "precision='fp32' (default) or pass allow_lossy_ddim=True" % self.precision)
         # parity runs draw every noise tensor on the CPU, one tensor per reference draw, in the reference's order
         self.noise_on_cpu = bool(noise_on_cpu)
+        self.noise_source = None  # callable(shape) -> CPU tensor: one stream per sample of a batch (parity tests)
         self.enforce_class_input = enforce_class_input
         self.custom_steps, self.es_steps = custom_steps, es_steps
         self.refine_steps, self.refine_iterations = refine_steps, refine_iterations
@@ -100,6 +101,8 @@ class DDPMDDIMWrapper(torch.nn.Module):
         self._anchor = torch.nn.Parameter(torch.zeros(1, device=self.engine.device), requires_grad=True)
 
     def _randn(self, n, shape):
+        if self.noise_source is not None:
+            return torch.stack([self.noise_source(tuple(shape)) for _ in range(n)], 0).to(self.device, torch.float32)
         if self.noise_on_cpu:
             return torch.stack([torch.randn(shape) for _ in range(n)], 0).to(self.device)
         return torch.randn((n,) + tuple(shape), device=self.device)
