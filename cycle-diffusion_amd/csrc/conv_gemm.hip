@@ -82,6 +82,12 @@ __device__ __forceinline__ unsigned long long probe_time() {
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
   return t;
 }
+// the 100 MHz reference clock: the same origin on every CU (s_memtime counters are per-CU), calibrates ticks -> us
+__device__ __forceinline__ unsigned long long probe_realtime() {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
 #define CD_PROBE_ONLY(...) __VA_ARGS__
 #else
 #define CD_PROBE_ONLY(...)
@@ -100,6 +106,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   CD_PROBE_ONLY(
+  const unsigned long long pr_rt0 = probe_realtime();
   unsigned long long pr_t0 = probe_time(), pr_prol = 0, pr_first = 0, pr_wait = 0, pr_comp = 0, pr_maxw = 0, pr_loop = 0,
                      pr_drain = 0, pr_stage = 0, pr_rows = 0, pr_issued = 0, pr_last = 0;
   unsigned* pr_log = (unsigned*)(smem + T::LDS_BYTES) + wave * 64;  // (arrive, pass) of the first 32 K steps
@@ -505,6 +512,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
           for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += bf2f(rp[e]);
         }
       }
+      CD_PROBE_ONLY(if (!(p.dbg & 1)))
       if (p.out_f32) {
         float* op = (float*)outp + (int64_t)m * p.out_ld + on;
         if (nvalid == 8 && ((p.out_ld & 3) == 0)) {
@@ -523,6 +531,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
           for (int e = 0; e < 8; ++e) if (e < nvalid) op[e] = f2bf(v[e]);
         }
       }
+      CD_PROBE_ONLY(if (p.dbg & 1) { if (v[0] == 1.2345e-33f) ((float*)outp)[0] = v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7]; })
       if (p.stats) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
@@ -558,7 +567,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
       if (lane == 0) {
         o[0] = pr_t0; o[1] = pr_prol; o[2] = pr_first; o[3] = pr_wait; o[4] = pr_comp; o[5] = pr_maxw; o[6] = pr_loop;
         o[7] = pr_drain; o[8] = pr_stage; o[9] = pr_rows; o[10] = pr_issued; o[11] = pr_done; o[12] = kt1 - kt0;
-        o[13] = ((unsigned long long)xcc << 32) | hwid; o[14] = tile; o[15] = 0;
+        o[13] = ((unsigned long long)xcc << 32) | hwid; o[14] = pr_rt0; o[15] = probe_realtime();
       }
       ((unsigned*)(o + 16))[lane] = pr_log[lane];  // the log lies beyond the tile's LDS: the epilogue did not touch it
     }
@@ -902,6 +911,10 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   id &= 0xff;
   if (pk.splitk > 1 && !pk.sk_scratch) { pk.sk_scratch = g_conv_splitk.scratch; pk.sk_flags = g_conv_splitk.flags; }
   pk.probe = g_conv_probe;
+#ifdef CD_PROBE
+  if (const char* e = getenv("CYCLEDIFF_PROBE_DBG")) pk.dbg = atoi(e);
+  if (pk.dbg & 2) pk.stats = nullptr;
+#endif
   static const CfgInfo kLinStreamCfg = {kLinStreamTile, 256, 64, 64, "lin_stream 256 x N, K = 320"};
   const CfgInfo* ci = nullptr;
   if (id == kLinStreamTile) {

@@ -95,6 +95,7 @@ struct ConvGemmParams {
   // phase-timing build only (-DCD_PROBE, lib/libcyclediff_probe.so; scripts/probe_report.py): every wave leaves
   // kProbeWords 64-bit words of s_memtime stamps here, [block][wave][kProbeWords]; null = off
   unsigned long long* probe = nullptr;
+  int dbg = 0;  // probe build: 1 = the epilogue skips its global stores, 2 = skips the statistics (CYCLEDIFF_PROBE_DBG)
 };
 constexpr int kProbeWords = 48;
 extern thread_local unsigned long long* g_conv_probe;  // picked up by launch_conv_gemm in the probe build

@@ -15,16 +15,22 @@ import sys
 import numpy as np
 
 W = 48
+# MFMAs (32x32x16, 32 cycles each) one wave issues per 64-deep K step; x waves per SIMD below
+MFMA_PER_STEP = {"256x320 w4x2 s2": 40, "128x320 w4x2 s2": 20, "256x256 w4x2 s2": 32, "256x128 w4x2 s3": 16}
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # name, B, H, C0, C1, N, k, act (| 0x100 residual, | 0x200 statistics), tiles
 CASES = [
-    ("conv3 320>320 @64 B32", 32, 64, 320, 0, 320, 3, 0x200, [20, 23, 21]),
-    ("conv3 320>320 @64 B32 plain", 32, 64, 320, 0, 320, 3, 0, [20]),
-    ("conv3 640>320 cat @64 B32", 32, 64, 320, 320, 320, 3, 0x200, [20]),
-    ("lin 640>640 @32 B32", 32, 32, 640, 0, 640, 1, 0x100, [20, 23, 22, 5]),
-    ("conv3 1280>1280 @16 B32", 32, 16, 1280, 0, 1280, 3, 0x200, [20, 23]),
-    ("conv3 640>640 @32 B32", 32, 32, 640, 0, 640, 3, 0x200, [20]),
+    # (..., tiles, probe-build debug bits: 1 = epilogue without global stores, 2 = without statistics)
+    ("conv3 320>320 @64 B32 +stats", 32, 64, 320, 0, 320, 3, 0x200, [20, 23], 0),
+    ("conv3 320>320 @64 B32 +stats, NO STORES", 32, 64, 320, 0, 320, 3, 0x200, [20], 1),
+    ("conv3 320>320 @64 B32 plain", 32, 64, 320, 0, 320, 3, 0, [20], 0),
+    ("conv3 320>320 @64 B32 plain, NO STORES", 32, 64, 320, 0, 320, 3, 0, [20], 1),
+    ("conv3 320>320 @64 B32 +resid +stats", 32, 64, 320, 0, 320, 3, 0x300, [20], 0),
+    ("conv3 640>320 cat @64 B32 +stats", 32, 64, 320, 320, 320, 3, 0x200, [20], 0),
+    ("lin 640>640 @32 B32 +resid", 32, 32, 640, 0, 640, 1, 0x100, [20, 22], 0),
+    ("conv3 1280>1280 @16 B32 +stats", 32, 16, 1280, 0, 1280, 3, 0x200, [20], 0),
+    ("conv3 640>640 @32 B32 +stats", 32, 32, 640, 0, 640, 3, 0x200, [20], 0),
 ]
 
 
@@ -44,25 +50,28 @@ def report(path, out=sys.stdout):
         print(head, "\n  no stamps (product build?)", file=out)
         return
     t0, prol, first, swait, scomp, maxw, loop, drain, stage, rows, issued, done, nst = (live[:, i].astype(np.float64) for i in range(13))
-    span = done.max() - t0.min()
-    tick_per_us = span / (ms * 1e3)  # the probed launch against the unprobed average: a calibration, not a measurement
-    us = lambda x: x / tick_per_us
     xcc = (live[:, 13] >> np.uint64(32)).astype(np.int64) & 0xf
     hw = live[:, 13].astype(np.int64) & 0xffffffff
-    cu = (hw >> 8) & 0xf
-    se = (hw >> 13) & 0x7
-    simd = (hw >> 4) & 0x3
-    # rounds: a CU's second workgroup starts when its first has ended
-    start = us(t0 - t0.min())
+    # s_memtime counters of different XCDs have different origins: time is taken relative to the XCD's first entry, and
+    # the tick rate from the XCD's own span (first entry -> last store landed) against the launch duration
+    # s_memtime counters are per CU (different origins): phases are differences inside one wave; the 100 MHz
+    # s_memrealtime stamps (same origin everywhere) calibrate ticks -> us and place the waves on one time axis
+    rt0, rt1 = live[:, 14].astype(np.float64), live[:, 15].astype(np.float64)
+    rate = (done - t0) / np.maximum(rt1 - rt0, 1.0) * 100.0  # ticks per us, per wave
+    tick_per_us = float(np.median(rate))
+    us = lambda x: x / tick_per_us
+    start = (rt0 - rt0.min()) / 100.0
+    base = t0 - start * tick_per_us
     rnd = np.zeros(len(start), dtype=int)
     order = np.sort(start)
     gaps = np.diff(order)
-    if len(gaps) and gaps.max() > 0.25 * us(span):
+    if len(gaps) and gaps.max() > 0.2 * ms * 1e3:
         cut = order[np.argmax(gaps)] + gaps.max() / 2
         rnd = (start > cut).astype(int)
     print(head, file=out)
-    print("  waves %d  span of the probed launch %.0f ticks = %.1f ticks/us against the unprobed %.1f us  (XCCs seen %s)" % (
-        len(live), span, tick_per_us, ms * 1e3, sorted(set(xcc.tolist()))), file=out)
+    print("  waves %d  s_memtime %.0f ticks/us = shader clock %.2f GHz (p5 %.2f, p95 %.2f over waves); launch span by the 100 MHz "
+          "clock %.1f us, average launch %.1f us" % (len(live), tick_per_us, tick_per_us / 1e3, np.percentile(rate, 5) / 1e3,
+                                                    np.percentile(rate, 95) / 1e3, (rt1.max() - rt0.min()) / 100.0, ms * 1e3), file=out)
     n = nst.mean()
 
     def line(name, v, mask):
@@ -72,7 +81,7 @@ def report(path, out=sys.stdout):
     for r in sorted(set(rnd.tolist())):
         m = rnd == r
         print("  round %d: %d waves, start %.1f .. %.1f us, end %.1f .. %.1f us after the first wave's entry" % (
-            r, m.sum(), start[m].min(), start[m].max(), us(done[m] - t0.min()).min(), us(done[m] - t0.min()).max()), file=out)
+            r, m.sum(), start[m].min(), start[m].max(), us(done[m] - base[m]).min(), us(done[m] - base[m]).max()), file=out)
         line("entry -> prologue issued", prol - t0, m)
         line("prologue issued -> first tile", first - prol, m)
         line("K loop (first tile -> last MFMA)", loop - first, m)
@@ -87,6 +96,10 @@ def report(path, out=sys.stdout):
         line("epilogue total (drain -> issued)", issued - drain, m)
         line("store tail (issued -> landed)", done - issued, m)
         line("whole wave", done - t0, m)
+        mf = 32.0 * nst[m].mean() * MFMA_PER_STEP.get(head.split('cfg="')[1].split('"')[0], 0) * 2  # two waves share a SIMD
+        if mf:
+            print("    MFMA pipe time of the tile's K loop %.2f us = %.0f %% of the whole wave" % (
+                mf / tick_per_us, 100.0 * mf / (done[m] - t0[m]).mean()), file=out)
     # one wave's first 32 K steps
     i = len(live) // 3
     lg = live[i, 16:48].view(np.uint32).astype(np.float64).reshape(32, 2)
@@ -106,8 +119,9 @@ def _worker(outdir, probe):
     import cycle_diffusion_amd as cda
     from cycle_diffusion_amd._ffi import check
     eng = cda.Engine("cuda:0", workspace_bytes=8 << 30)
-    for ci, (name, B, hw, c0, c1, n, k, act, tiles) in enumerate(CASES):
+    for ci, (name, B, hw, c0, c1, n, k, act, tiles, dbg) in enumerate(CASES):
         for tile in tiles:
+            os.environ["CYCLEDIFF_PROBE_DBG"] = str(dbg)
             if probe:
                 os.environ["CYCLEDIFF_PROBE_OUT"] = os.path.join(outdir, "c%d_t%d.bin" % (ci, tile))
             ms = C.c_float()
@@ -136,7 +150,7 @@ def run(outdir):
         if r.returncode != 0:
             print(r.stderr[-2000:])
     with open(os.path.join(outdir, "report.txt"), "w") as rep:
-        for ci, (name, B, hw, c0, c1, n, k, act, tiles) in enumerate(CASES):
+        for ci, (name, B, hw, c0, c1, n, k, act, tiles, dbg) in enumerate(CASES):
             for tile in tiles:
                 fl = 2.0 * B * hw * hw * n * k * k * (c0 + c1)
                 ms_prod, ms_probe = res.get((ci, tile, False), float("nan")), res.get((ci, tile, True), float("nan"))
