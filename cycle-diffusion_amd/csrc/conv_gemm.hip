@@ -141,8 +141,16 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
   // into the zero padding (or beyond M) carry an out-of-range offset, for which the buffer unit
   // returns zeros into LDS. The K loop therefore issues no per-lane address arithmetic.
   constexpr unsigned kRange = 0x7fffffffu, kInvalid = 0x80000000u;
-  const bf16_t* base0 = p.src0 + (int64_t)zb * p.a_bs;
-  const bf16_t* base1 = p.src1 ? p.src1 + (int64_t)zb * p.a_bs : base0;
+  // A buffer offset has 31 usable bits, an activation tensor may be larger (the KL-f8 decoder's 256-channel 512 x 512
+  // level is 128 MiB per sample: 2 GiB at batch 16). The descriptor base therefore starts at the first SAMPLE this tile
+  // touches and the lane offsets are relative to it: a tile's rows span a few samples at most.
+  const int HWo = p.Hout * p.Wout;
+  const bool pow2 = ((HWo & (HWo - 1)) == 0) && ((p.Wout & (p.Wout - 1)) == 0);
+  const int sh_hw = 31 - __builtin_clz(HWo), sh_w = 31 - __builtin_clz(p.Wout);
+  const int b_first = pow2 ? (m0 >> sh_hw) : (m0 / HWo);
+  const int64_t samp0 = (int64_t)b_first * p.Hs * p.Ws;
+  const bf16_t* base0 = p.src0 + (int64_t)zb * p.a_bs + samp0 * p.ld0;
+  const bf16_t* base1 = p.src1 ? p.src1 + (int64_t)zb * p.a_bs + samp0 * p.ld1 : base0;
   const __amdgpu_buffer_rsrc_t rsw =
       __builtin_amdgcn_make_buffer_rsrc((void*)(p.wgt + (int64_t)zb * p.w_bs), 0, kRange, 0x00020000);
 
@@ -151,9 +159,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
   const int pchunk = lane % CPR; // physical 16-B chunk this lane fills
   int a_iy0[A_IPW], a_ix0[A_IPW], a_boff[A_IPW], a_lc8[A_IPW];
   unsigned a_voff[A_IPW];
-  const int HWo = p.Hout * p.Wout;
-  const bool pow2 = ((HWo & (HWo - 1)) == 0) && ((p.Wout & (p.Wout - 1)) == 0);
-  const int sh_hw = 31 - __builtin_clz(HWo), sh_w = 31 - __builtin_clz(p.Wout);
 #pragma unroll
   for (int i = 0; i < A_IPW; ++i) {
     const int row = (i * NW + wave) * RPI + srow;
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
       }
       a_iy0[i] = oy * p.stride - p.pad_t;
       a_ix0[i] = ox * p.stride - p.pad_l;
-      a_boff[i] = b * p.Hs * p.Ws;
+      a_boff[i] = (b - b_first) * p.Hs * p.Ws;
     } else {
       a_iy0[i] = -(1 << 28);  // always out of range -> zeros
       a_ix0[i] = 0;
@@ -199,7 +204,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
   const int kt1 = (kt0 + kper < nk) ? kt0 + kper : nk;
   // K-step cursor (uniform): tap (kr, kss) and channel offset kc within the concatenated channels
   int kr, kss, kc;
-  {
+  const int ntaps = p.KH * p.KW;
+  const bool chmajor = p.korder != 0 && ntaps > 1;
+  if (chmajor) {  // step kt = (channel slice kt / ntaps, tap kt % ntaps)
+    const int slice = kt0 / ntaps, tap = kt0 - slice * ntaps;
+    kc = slice * BK;
+    kr = tap / p.KW;
+    kss = tap - kr * p.KW;
+  } else {
     const int k_el = kt0 * BK;
     const int tap = k_el / Ctot;
     kc = k_el - tap * Ctot;
@@ -221,12 +233,24 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
   auto prepare = [&](int kt) {
     st_live = kt < kt1;
     const int c_kc = kc, c_kr = kr, c_kss = kss;
-    kc += BK;
-    if (kc >= Ctot) {
-      kc = 0;
-      if (++kss >= p.KW) { kss = 0; ++kr; }
+    {  // cursor advance in select form (if / else stores to captured state end up as indexed stores to scratch)
+      // channel-major: tap inner, channel slice outer
+      const bool a_wk = c_kss + 1 >= p.KW;
+      const int a_kss = a_wk ? 0 : c_kss + 1;
+      const bool a_wr = a_wk && (c_kr + 1 >= p.KH);
+      const int a_kr = a_wr ? 0 : c_kr + (a_wk ? 1 : 0);
+      const int a_kc = c_kc + (a_wr ? BK : 0);
+      // tap-major: channel slice inner, tap outer
+      const bool b_wc = c_kc + BK >= Ctot;
+      const int b_kc = b_wc ? 0 : c_kc + BK;
+      const bool b_wk = b_wc && (c_kss + 1 >= p.KW);
+      const int b_kss = b_wk ? 0 : c_kss + (b_wc ? 1 : 0);
+      const int b_kr = c_kr + (b_wk ? 1 : 0);
+      kc = chmajor ? a_kc : b_kc;
+      kss = chmajor ? a_kss : b_kss;
+      kr = chmajor ? a_kr : b_kr;
     }
-    if (st_live && (c_kc == 0 || c_kc == p.C0 || st_force)) {  // new filter tap / second concat source
+    if (st_live && (chmajor || c_kc == 0 || c_kc == p.C0 || st_force)) {  // new filter tap / second concat source
       st_force = false;
       const int ld = (c_kc < p.C0) ? p.ld0 : p.ld1;
 #pragma unroll
@@ -241,7 +265,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
     const bool first = c_kc < p.C0;
     st_base = first ? base0 : base1;
     st_soffa = (first ? c_kc : c_kc - p.C0) * 2;
-    st_soffb = st_live ? kt * (BK * 2) : 0;
+    st_soffb = st_live ? (chmajor ? ((c_kr * p.KW + c_kss) * Ctot + c_kc) * 2 : kt * (BK * 2)) : 0;
   };
   auto issue = [&](int idx, int buf) {  // idx is a compile-time constant after unrolling
     if (idx < A_IPW) {
@@ -393,6 +417,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
             const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsp, off, 0, kSc1));
             acc[i][j][4 * q] += v[0]; acc[i][j][4 * q + 1] += v[1];
             acc[i][j][4 * q + 2] += v[2]; acc[i][j][4 * q + 3] += v[3];
+            // at most one 32 x 32 block of partials in flight: with 160 accumulators live the scheduler would otherwise batch
+            // enough loads to spill what the epilogue needs later
+            if (q == 3 && MT * NT >= 8) __builtin_amdgcn_sched_barrier(0);
           }
     }
   }
@@ -403,6 +430,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
   // compiler's order). A register-resident variant (transposed MFMA blocks + v_permlane32_swap, no LDS round trip)
   // measured SLOWER: its row-per-lane 16-byte stores touch 32-64 lines per instruction (DESIGN.md optimisation log).
   constexpr int CW = T::CW, CJ = CW / 32;  // chunk width in columns / in 32-column MFMA blocks
+  // the epilogue's lane geometry starts from an opaque copy of the lane id, so that none of it is computed (and kept in
+  // registers) ahead of the K loop or the split-K fix-up, where the tiles with 128+ accumulators have nothing to spare
+  int lane_ep = lane;
+  asm volatile("" : "+v"(lane_ep));
   float* E = (float*)smem + wave * (TM * T::EPI_LD);
   const bool geglu = (p.act == ACT_GEGLU);
   char* outp = (char*)p.out + (int64_t)zb * p.o_bs * (p.out_f32 ? 4 : 2);
@@ -429,7 +460,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
     // half produces output, at column (n/64)*32 + n%32.
     const int vpr = geglu ? 4 : (cw / 8);  // 8-wide vectors per row handled
     const int rpp = 64 / vpr;              // rows per pass
-    const int vr = lane / vpr, vc = lane % vpr;
+    const int vr = lane_ep / vpr, vc = lane_ep % vpr;
     // column-only quantities are the same for every row this lane handles: hoist them out of the row loop
     const int col = vc * 8;                            // column inside the chunk
     const int n = n0 + wn * TN + jc * 32 + col;        // packed column
@@ -446,6 +477,99 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
     float ssum[8], ssq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+    // ---- the common flavour (16-bit output, no activation: every ResBlock / transformer projection of the U-Nets and
+    // first stages): one 32-row block at a time with all its LDS reads and residual loads issued before any arithmetic
+    // (round 4 phase timing, profiles/r4_conv_tile_phase_timing.txt: the one-pass-at-a-time loop below spent 0.8 k cycles per
+    // 8-row pass on exposed LDS / L2 latency, and the statistics another 0.45 k on a 48-shuffle butterfly plus sixteen
+    // 8-lane stores). GroupNorm statistics of the block: per-lane partial sums over the block's passes, transposed through
+    // the LDS rows just consumed, column sums by the lane that owns the column -> two dense 256-byte stores.
+    const bool fast = !geglu && !p.out_f32 && !p.resid_f32 && p.act == ACT_NONE && (p.N & 7) == 0 && (p.out_ld & 7) == 0 &&
+                      (!p.resid || (p.resid_ld & 7) == 0) && (!p.rowvec || p.rows_per_vec >= p.M || (p.rows_per_vec & 31) == 0);
+    if (fast) {
+      constexpr int LD = T::EPI_LD;
+      const int RPP = 64 / (cw / 8), NP = 32 / RPP;  // rows per pass, passes per 32-row block (compile-time: cw is)
+      const bool colok = n < p.N;
+      bf16_t* const ocol = (bf16_t*)outp + n;
+      const bf16_t* const rcol = p.resid ? p.resid + (int64_t)zb * p.o_bs + n : nullptr;
+#pragma unroll
+      for (int rb = 0; rb < TM / 32; ++rb) {
+        const int mb = m0 + wm * TM + rb * 32;  // first row of the block
+        if (mb < p.M) {                         // (uniform) ragged M: whole blocks beyond the last row do nothing
+          f32x4 lo[4], hi[4];
+          uint4 rr[4];
+          bool ok[4];
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps)
+            if (ps < NP) {
+              const float* er = E + (rb * 32 + ps * RPP + vr) * LD + col;
+              lo[ps] = *(const f32x4*)er;
+              hi[ps] = *(const f32x4*)(er + 4);
+            }
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps)
+            if (ps < NP) {
+              const int m = mb + ps * RPP + vr;
+              ok[ps] = colok && m < p.M;
+              rr[ps] = (uint4){0u, 0u, 0u, 0u};
+              if (rcol && ok[ps]) rr[ps] = *(const uint4*)(rcol + (int64_t)m * p.resid_ld);
+            }
+          float add[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) add[e] = bias_v[e];
+          if (p.rowvec && colok) {  // one time-embedding row per image; a 32-row block lies inside one image
+            const int rvi = (p.rows_per_vec >= p.M) ? 0 : mb / p.rows_per_vec;
+            const float* rv = p.rowvec + (int64_t)rvi * p.rowvec_ld + n;
+            const f32x4 r0v = *(const f32x4*)rv, r1v = *(const f32x4*)(rv + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { add[e] += r0v[e]; add[4 + e] += r1v[e]; }
+          }
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps)
+            if (ps < NP) {
+              float v[8], rf[8];
+              unpack8(rr[ps], rf);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[e] = lo[ps][e] + add[e]; v[4 + e] = hi[ps][e] + add[4 + e]; }
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += rf[e];
+              if (ok[ps]) {
+                CD_PROBE_ONLY(if (!(p.dbg & 1)))
+                *(uint4*)(ocol + (int64_t)(mb + ps * RPP + vr) * p.out_ld) = pack8(v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+              }
+            }
+          if (p.stats) {
+            float* S = E + rb * 32 * LD;  // the block's rows are in registers: 2 x 512 floats of them as scratch
+            __builtin_amdgcn_wave_barrier();
+            *(f32x4*)(S + vr * cw + col) = (f32x4){ssum[0], ssum[1], ssum[2], ssum[3]};
+            *(f32x4*)(S + vr * cw + col + 4) = (f32x4){ssum[4], ssum[5], ssum[6], ssum[7]};
+            *(f32x4*)(S + 512 + vr * cw + col) = (f32x4){ssq[0], ssq[1], ssq[2], ssq[3]};
+            *(f32x4*)(S + 512 + vr * cw + col + 4) = (f32x4){ssq[4], ssq[5], ssq[6], ssq[7]};
+            __builtin_amdgcn_wave_barrier();
+            const int nc0 = n0 + wn * TN + jc * 32;  // first column of the chunk
+            float* sp = p.stats + ((int64_t)zb * ((p.M + 31) >> 5) + (mb >> 5)) * 2 * p.N + nc0;
+            if (cw == 64) {
+              float s = 0.f, q = 0.f;
+#pragma unroll
+              for (int k = 0; k < 8; ++k) { s += S[k * 64 + lane_ep]; q += S[512 + k * 64 + lane_ep]; }
+              if (nc0 + lane_ep < p.N) { sp[lane_ep] = s; sp[p.N + lane_ep] = q; }
+            } else {  // 32-column chunk: lanes 0-31 own the sums, 32-63 the sums of squares
+              const int arr = lane_ep >> 5, c = lane_ep & 31;
+              float s = 0.f;
+#pragma unroll
+              for (int k = 0; k < 16; ++k) s += S[arr * 512 + k * 32 + c];
+              if (nc0 + c < p.N) sp[arr * p.N + c] = s;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+          }
+        }
+      }
+      CD_PROBE_ONLY(pr_rows += probe_time() - pr_c1;)
+      continue;
+    }
     for (int r0 = 0; r0 < TM; r0 += rpp) {
       const int row = r0 + vr;
       const int m = m0 + wm * TM + row;
@@ -911,6 +1035,8 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   id &= 0xff;
   if (pk.splitk > 1 && !pk.sk_scratch) { pk.sk_scratch = g_conv_splitk.scratch; pk.sk_flags = g_conv_splitk.flags; }
   pk.probe = g_conv_probe;
+  static const int korder_env = [] { const char* e = getenv("CYCLEDIFF_KORDER"); return e ? atoi(e) : 0; }();
+  if (korder_env) pk.korder = korder_env;
 #ifdef CD_PROBE
   if (const char* e = getenv("CYCLEDIFF_PROBE_DBG")) pk.dbg = atoi(e);
   if (pk.dbg & 2) pk.stats = nullptr;

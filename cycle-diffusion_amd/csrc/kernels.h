@@ -95,6 +95,10 @@ struct ConvGemmParams {
   // phase-timing build only (-DCD_PROBE, lib/libcyclediff_probe.so; scripts/probe_report.py): every wave leaves
   // kProbeWords 64-bit words of s_memtime stamps here, [block][wave][kProbeWords]; null = off
   unsigned long long* probe = nullptr;
+  // order of the K steps of a KH x KW > 1 convolution: 0 = tap-major (all channels of a filter tap, then the next tap),
+  // 1 = channel-major (the KH*KW taps of one BK-channel slice, then the next slice: the re-reads of an activation line by
+  // neighbouring taps follow each other within KH*KW steps and hit the XCD's L2)
+  int korder = 0;
   int dbg = 0;  // probe build: 1 = the epilogue skips its global stores, 2 = skips the statistics (CYCLEDIFF_PROBE_DBG)
 };
 constexpr int kProbeWords = 48;

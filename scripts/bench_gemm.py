@@ -58,6 +58,8 @@ for name, hw, c0, c1, n, k, stride, up, act, calls in SHAPES:
     ho = hw * 2 if up else hw // stride
     fl = 2.0 * B * ho * ho * n * k * k * (c0 + c1)
     res = {}
+    if act != 3:
+        act |= int(os.environ.get("GEMM_ACT_OR", "0"), 0)  # | 0x100 in-place residual, | 0x200 fused GroupNorm statistics
     for tile in TILES:
         if act == 3 and tile in (3, 8, 15, 18):
             continue

@@ -108,6 +108,32 @@ def test_kl_f8_vae_full_size_vs_oracle(engine, report, sd_vae):
     assert r2[0] < 1e-2 * FMT and r2[1] < 1e-2 * FMT, r2
 
 
+@pytest.mark.parametrize("B", [17, 33])
+def test_kl_f8_vae_batches_beyond_2_gib_per_tensor(engine, report, sd_vae, B):
+    """A 512 x 512 batch of 17 makes the decoder's 256-channel 512 x 512 activations (128 MiB per sample) larger than
+    2 GiB, a batch of 33 the 128-channel ones of encoder and decoder: beyond the 31 usable bits of a buffer offset. Until
+    round 4 the implicit-GEMM gather took its lane offsets from the start of the TENSOR, so samples >= 16 of a folded
+    decode read zeros (found by test_c2_ensemble_decode_call_of_25_members_vs_members_alone; the benchmark's folded
+    B' = 32 decode was affected, its B = 1 parity fixtures were not). Offsets are now relative to the first sample a tile
+    touches. Every sample of the batch must equal its one-sample result to 16-bit rounding (same tiles: bit-equal)."""
+    net, _sd = sd_vae
+    g = torch.Generator().manual_seed(40 + B)
+    z = torch.randn(B, 4, 64, 64, generator=g).cuda()
+    img = (torch.rand(B, 3, 512, 512, generator=g) * 2 - 1).cuda()
+    pick = sorted({0, 15, 16, 17 % B, 31 % B, 32 % B, B - 1})
+    dec = engine.vae_decode(net, z, scale=0.18215, out_mul=0.5, out_add=0.5)
+    enc = engine.vae_encode(net, img, sample=False, scale=0.18215)
+    worst_d, worst_e = 0.0, 0.0
+    for i in pick:
+        d1 = engine.vae_decode(net, z[i:i + 1], scale=0.18215, out_mul=0.5, out_add=0.5)
+        e1 = engine.vae_encode(net, img[i:i + 1], sample=False, scale=0.18215)
+        worst_d = max(worst_d, ((dec[i:i + 1] - d1).abs().max() / d1.abs().max()).item())
+        worst_e = max(worst_e, ((enc[i:i + 1] - e1).abs().max() / e1.abs().max()).item())
+    report.add("fullsize/kl_f8_vae_batch_%d_vs_alone" % B, dec_rel_to_max=worst_d, enc_rel_to_max=worst_e, samples=pick)
+    assert torch.isfinite(dec).all() and torch.isfinite(enc).all()
+    assert worst_d < 5e-3 * FMT and worst_e < 5e-3 * FMT, (worst_d, worst_e)  # measured 1.0-1.6e-3 / 4-7e-4 at batch 16
+
+
 def test_c2_cycle_batch_independence_determinism(engine, report, sd_unet):
     """DPM-Encoder + DDIM decode at the C2 latent size, 20 steps: (1) same-text decode returns x0, (2) sample 0
     encoded alone equals sample 0 encoded in a batch of 2 up to 16-bit rounding (tile / split-K choices follow
