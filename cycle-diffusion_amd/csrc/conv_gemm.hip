@@ -147,7 +147,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
   const int HWo = p.Hout * p.Wout;
   const bool pow2 = ((HWo & (HWo - 1)) == 0) && ((p.Wout & (p.Wout - 1)) == 0);
   const int sh_hw = 31 - __builtin_clz(HWo), sh_w = 31 - __builtin_clz(p.Wout);
-  const int b_first = pow2 ? (m0 >> sh_hw) : (m0 / HWo);
+  int b_first = pow2 ? (m0 >> sh_hw) : (m0 / HWo);
+  CD_PROBE_ONLY(if (p.dbg & 4) b_first = 0;)
   const int64_t samp0 = (int64_t)b_first * p.Hs * p.Ws;
   const bf16_t* base0 = p.src0 + (int64_t)zb * p.a_bs + samp0 * p.ld0;
   const bf16_t* base1 = p.src1 ? p.src1 + (int64_t)zb * p.a_bs + samp0 * p.ld1 : base0;
@@ -162,7 +163,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
 #pragma unroll
   for (int i = 0; i < A_IPW; ++i) {
     const int row = (i * NW + wave) * RPI + srow;
-    const int m = m0 + row;
+    int m = m0 + row;
+    CD_PROBE_ONLY(if (p.dbg & 4) m = (m0 & 0x3ff) + row;)  // timing experiment: every tile gathers A from the first images (L2-hot)
     a_lc8[i] = (pchunk ^ ((row >> T::SWZ_SHIFT) & (CPR - 1))) * 8;
     a_voff[i] = kInvalid;
     if (m < p.M) {
@@ -204,14 +206,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
   const int kt1 = (kt0 + kper < nk) ? kt0 + kper : nk;
   // K-step cursor (uniform): tap (kr, kss) and channel offset kc within the concatenated channels
   int kr, kss, kc;
-  const int ntaps = p.KH * p.KW;
-  const bool chmajor = p.korder != 0 && ntaps > 1;
-  if (chmajor) {  // step kt = (channel slice kt / ntaps, tap kt % ntaps)
-    const int slice = kt0 / ntaps, tap = kt0 - slice * ntaps;
-    kc = slice * BK;
-    kr = tap / p.KW;
-    kss = tap - kr * p.KW;
-  } else {
+  {
     const int k_el = kt0 * BK;
     const int tap = k_el / Ctot;
     kc = k_el - tap * Ctot;
@@ -233,24 +228,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
   auto prepare = [&](int kt) {
     st_live = kt < kt1;
     const int c_kc = kc, c_kr = kr, c_kss = kss;
-    {  // cursor advance in select form (if / else stores to captured state end up as indexed stores to scratch)
-      // channel-major: tap inner, channel slice outer
-      const bool a_wk = c_kss + 1 >= p.KW;
-      const int a_kss = a_wk ? 0 : c_kss + 1;
-      const bool a_wr = a_wk && (c_kr + 1 >= p.KH);
-      const int a_kr = a_wr ? 0 : c_kr + (a_wk ? 1 : 0);
-      const int a_kc = c_kc + (a_wr ? BK : 0);
-      // tap-major: channel slice inner, tap outer
-      const bool b_wc = c_kc + BK >= Ctot;
-      const int b_kc = b_wc ? 0 : c_kc + BK;
-      const bool b_wk = b_wc && (c_kss + 1 >= p.KW);
-      const int b_kss = b_wk ? 0 : c_kss + (b_wc ? 1 : 0);
-      const int b_kr = c_kr + (b_wk ? 1 : 0);
-      kc = chmajor ? a_kc : b_kc;
-      kss = chmajor ? a_kss : b_kss;
-      kr = chmajor ? a_kr : b_kr;
+    kc += BK;
+    if (kc >= Ctot) {
+      kc = 0;
+      if (++kss >= p.KW) { kss = 0; ++kr; }
     }
-    if (st_live && (chmajor || c_kc == 0 || c_kc == p.C0 || st_force)) {  // new filter tap / second concat source
+    if (st_live && (c_kc == 0 || c_kc == p.C0 || st_force)) {  // new filter tap / second concat source
       st_force = false;
       const int ld = (c_kc < p.C0) ? p.ld0 : p.ld1;
 #pragma unroll
@@ -265,7 +248,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
     const bool first = c_kc < p.C0;
     st_base = first ? base0 : base1;
     st_soffa = (first ? c_kc : c_kc - p.C0) * 2;
-    st_soffb = st_live ? (chmajor ? ((c_kr * p.KW + c_kss) * Ctot + c_kc) * 2 : kt * (BK * 2)) : 0;
+    st_soffb = st_live ? kt * (BK * 2) : 0;
   };
   auto issue = [&](int idx, int buf) {  // idx is a compile-time constant after unrolling
     if (idx < A_IPW) {
@@ -292,76 +275,94 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
   const int frow = lane & 31;  // fragment row within a 32-row MFMA tile
   const int fhalf = lane >> 5; // which 8-wide k half this lane feeds
 
-  // ---- prologue: fill NSTAGE-1 ring slots
+  // ---- K loop. The ring holds NSTAGE tiles; fragments are read T::PF k-slices ahead of their MFMAs, ACROSS tile
+  // boundaries. The one workgroup barrier per K step therefore does not sit at the step boundary (where every wave would
+  // restart cold: refill issue, first fragment reads and their LDS latency with the matrix pipe idle - round 4 phase timing,
+  // profiles/r4_conv_tile_phase_timing_*.txt: 35 % of a step) but in the middle of the segment that issues the first reads
+  // of the NEXT tile, where each wave still holds MFMAs whose operands are in registers:
+  //   segment ks = KS - PF of step kt:  first half of the slice's MFMAs
+  //                                     s_waitcnt lgkmcnt(0) vmcnt(..) + s_barrier: every wave has finished READING tile kt
+  //                                       (its last slice was requested one segment earlier) and its pieces of tile kt+1
+  //                                       have landed -> slot of tile kt is free, tile kt+1 is readable by everyone
+  //                                     refill of that slot with tile kt+NSTAGE, second half of the MFMAs, reads of
+  //                                       slice 0 of tile kt+1
+  // 2-deep rings issue the whole refill right there (a full step to land, as before); deeper rings spread it over the KS
+  // segments that follow.
+  constexpr int PF = T::PF, SYNC = KS - PF, NMF = MT * NT, HALF = NMF / 2;
+  constexpr int SPREAD = (NSTAGE == 2) ? 1 : KS;
+  static_assert(SYNC >= 0 && (NSTAGE - 1) * LPT <= 63, "fragment prefetch depth / vmcnt field");
 #pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s) {
+  for (int s = 0; s < NSTAGE; ++s) {
     prepare(kt0 + s);
 #pragma unroll
     for (int l = 0; l < LPT; ++l) issue(l, s);
   }
-
-  int cur = 0;             // ring slot of tile kt
-  int nxt = NSTAGE - 1;    // ring slot the next prefetch goes to (= slot of tile kt-1)
   CD_PROBE_ONLY(pr_prol = probe_time(); pr_last = pr_prol;)
-  for (int kt = kt0; kt < kt1; ++kt) {
-    CD_PROBE_ONLY(const unsigned long long pr_arr = probe_time();)
-    // tile kt has landed when at most (NSTAGE-2) younger tiles (LPT loads each) are still in flight
-    wait_vmcnt_barrier<(NSTAGE - 2) * LPT>();
-    CD_PROBE_ONLY({
-      const unsigned long long now = probe_time();
-      if (kt == kt0) pr_first = now;
-      else { pr_comp += pr_arr - pr_last; pr_wait += now - pr_arr; if (now - pr_arr > pr_maxw) pr_maxw = now - pr_arr; }
-      if (kt - kt0 < 32 && lane == 0) { pr_log[2 * (kt - kt0)] = (unsigned)(pr_arr - pr_t0); pr_log[2 * (kt - kt0) + 1] = (unsigned)(now - pr_t0); }
-      pr_last = now;
-    })
-    // every wave has passed the barrier => everyone finished reading slot `nxt` (tile kt-1): refill it
-    prepare(kt + NSTAGE - 1);
-    const char* Ab = As + cur * T::A_BYTES;
-    const char* Bb = Bs + cur * T::B_BYTES;
-    bf16x8 af[KS][MT], bfr[KS][NT];
-    auto read_frags = [&](int ks) {
+  wait_vmcnt_barrier<(NSTAGE - 1) * LPT>();  // tile kt0 has landed everywhere
+  CD_PROBE_ONLY(pr_first = probe_time(); pr_last = pr_first;)
+
+  bf16x8 af[KS][MT], bfr[KS][NT];
+  auto read_frags = [&](int slot, int ks) {
+    const char* Ab = As + slot * T::A_BYTES;
+    const char* Bb = Bs + slot * T::B_BYTES;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int row = wm * TM + i * 32 + frow;
-        const int ch = (ks * 2 + fhalf) ^ ((row >> T::SWZ_SHIFT) & (CPR - 1));
-        af[ks][i] = *(const bf16x8*)(Ab + row * (BK * 2) + ch * 16);
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int row = wn * TN + j * 32 + frow;
-        const int ch = (ks * 2 + fhalf) ^ ((row >> T::SWZ_SHIFT) & (CPR - 1));
-        bfr[ks][j] = *(const bf16x8*)(Bb + row * (BK * 2) + ch * 16);
-      }
-    };
-    // segment 0: fragments of the first two k-slices; then per k-slice one pinned segment with its share
-    // of the staging loads, the slice's MFMAs (independent accumulators) and the reads two slices ahead
-    // 2-deep rings: the refill of the slot just released goes out in one burst right after the barrier, so it has
-    // the whole step to land (+5 % on the 128x64 / 128x128 s2 tiles); deeper rings have a step of slack already
-    // and do better with the loads spread over the MFMA segments (a burst costs them 8 %)
-    constexpr bool front = (NSTAGE == 2);
-    if (front) {
-#pragma unroll
-      for (int l = 0; l < LPT; ++l) issue(l, nxt);
+    for (int i = 0; i < MT; ++i) {
+      const int row = wm * TM + i * 32 + frow;
+      const int ch = (ks * 2 + fhalf) ^ ((row >> T::SWZ_SHIFT) & (CPR - 1));
+      af[ks][i] = *(const bf16x8*)(Ab + row * (BK * 2) + ch * 16);
     }
-    read_frags(0);
-    if (KS > 1 && T::PF > 1) read_frags(1);
-    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int row = wn * TN + j * 32 + frow;
+      const int ch = (ks * 2 + fhalf) ^ ((row >> T::SWZ_SHIFT) & (CPR - 1));
+      bfr[ks][j] = *(const bf16x8*)(Bb + row * (BK * 2) + ch * 16);
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < PF; ++q) read_frags(0, q);
+  __builtin_amdgcn_sched_barrier(0);
+
+  int cur = 0;   // ring slot of tile kt
+  int fill = 0;  // slot the spread refill goes to (the tile whose sync came last)
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int nslot = (cur + 1 == NSTAGE) ? 0 : cur + 1;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      if (!front) {
+      const int jrel = (ks - SYNC + KS) % KS;  // segments since the sync that opened the current refill
+      auto mfma_range = [&](int lo, int hi) __attribute__((always_inline)) {
 #pragma unroll
-      for (int l = (ks * LPT) / KS; l < ((ks + 1) * LPT) / KS; ++l) issue(l, nxt);
+        for (int n = 0; n < NMF; ++n)
+          if (n >= lo && n < hi) acc[n / NT][n % NT] = CD_MFMA_32x32x16(af[ks][n / NT], bfr[ks][n % NT], acc[n / NT][n % NT]);
+      };
+      if (ks == SYNC) {
+        mfma_range(0, HALF);
+        CD_PROBE_ONLY(const unsigned long long pr_arr = probe_time();)
+        // own LDS reads of tile kt done, own pieces of tile kt+1 landed ((NSTAGE-2) younger tiles may fly) -> barrier
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NSTAGE - 2) * LPT) : "memory");
+        CD_PROBE_ONLY({
+          const unsigned long long now = probe_time();
+          pr_comp += pr_arr - pr_last; pr_wait += now - pr_arr; if (now - pr_arr > pr_maxw) pr_maxw = now - pr_arr;
+          if (kt - kt0 < 32 && lane == 0) { pr_log[2 * (kt - kt0)] = (unsigned)(pr_arr - pr_t0); pr_log[2 * (kt - kt0) + 1] = (unsigned)(now - pr_t0); }
+          pr_last = now;
+        })
+        prepare(kt + NSTAGE);
+        fill = cur;
+#pragma unroll
+        for (int l = 0; l < LPT / SPREAD; ++l) issue(l, fill);
+        mfma_range(HALF, NMF);
+      } else {
+        if (SPREAD > 1 && (ks > SYNC || kt != kt0)) {  // this segment's share of the refill opened at the last sync
+#pragma unroll
+          for (int l = (jrel * LPT) / SPREAD; l < ((jrel + 1) * LPT) / SPREAD; ++l) issue(l, fill);
+        }
+        mfma_range(0, NMF);
       }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = CD_MFMA_32x32x16(af[ks][i], bfr[ks][j], acc[i][j]);
-      if (ks + T::PF < KS) read_frags(ks + T::PF);
+      // fragments PF slices ahead: of this tile, or (after the sync) of the next one
+      if (ks + PF < KS) read_frags(cur, ks + PF);
+      else read_frags(nslot, ks + PF - KS);
       __builtin_amdgcn_sched_barrier(0);
     }
-    nxt = cur;
-    cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+    cur = nslot;
   }
   CD_PROBE_ONLY(pr_loop = probe_time(); pr_comp += pr_loop - pr_last;)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the dummy tail loads before LDS is reused
@@ -1035,8 +1036,6 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   id &= 0xff;
   if (pk.splitk > 1 && !pk.sk_scratch) { pk.sk_scratch = g_conv_splitk.scratch; pk.sk_flags = g_conv_splitk.flags; }
   pk.probe = g_conv_probe;
-  static const int korder_env = [] { const char* e = getenv("CYCLEDIFF_KORDER"); return e ? atoi(e) : 0; }();
-  if (korder_env) pk.korder = korder_env;
 #ifdef CD_PROBE
   if (const char* e = getenv("CYCLEDIFF_PROBE_DBG")) pk.dbg = atoi(e);
   if (pk.dbg & 2) pk.stats = nullptr;

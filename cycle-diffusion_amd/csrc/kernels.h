@@ -95,11 +95,8 @@ struct ConvGemmParams {
   // phase-timing build only (-DCD_PROBE, lib/libcyclediff_probe.so; scripts/probe_report.py): every wave leaves
   // kProbeWords 64-bit words of s_memtime stamps here, [block][wave][kProbeWords]; null = off
   unsigned long long* probe = nullptr;
-  // order of the K steps of a KH x KW > 1 convolution: 0 = tap-major (all channels of a filter tap, then the next tap),
-  // 1 = channel-major (the KH*KW taps of one BK-channel slice, then the next slice: the re-reads of an activation line by
-  // neighbouring taps follow each other within KH*KW steps and hit the XCD's L2)
-  int korder = 0;
-  int dbg = 0;  // probe build: 1 = the epilogue skips its global stores, 2 = skips the statistics (CYCLEDIFF_PROBE_DBG)
+  int dbg = 0;  // probe build: 1 = the epilogue skips its global stores, 2 = skips the statistics, 4 = every tile gathers
+                // its A rows from the first 1024 + BM rows (an L2-resident operand: what would the K loop do without misses?)
 };
 constexpr int kProbeWords = 48;
 extern thread_local unsigned long long* g_conv_probe;  // picked up by launch_conv_gemm in the probe build

@@ -21,16 +21,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # name, B, H, C0, C1, N, k, act (| 0x100 residual, | 0x200 statistics), tiles
 CASES = [
-    # (..., tiles, probe-build debug bits: 1 = epilogue without global stores, 2 = without statistics)
+    # (..., tiles, probe-build debug bits: 1 = epilogue without global stores, 2 = without statistics, 4 = A operand of every
+    # tile gathered from the first rows of the tensor, i.e. L2-resident)
     ("conv3 320>320 @64 B32 +stats", 32, 64, 320, 0, 320, 3, 0x200, [20, 23], 0),
-    ("conv3 320>320 @64 B32 +stats, NO STORES", 32, 64, 320, 0, 320, 3, 0x200, [20], 1),
-    ("conv3 320>320 @64 B32 plain", 32, 64, 320, 0, 320, 3, 0, [20], 0),
+    ("conv3 320>320 @64 B32 +stats, A L2-RESIDENT", 32, 64, 320, 0, 320, 3, 0x200, [20, 23], 4),
     ("conv3 320>320 @64 B32 plain, NO STORES", 32, 64, 320, 0, 320, 3, 0, [20], 1),
+    ("conv3 320>320 @64 B32 plain, NO STORES, A L2-RESIDENT", 32, 64, 320, 0, 320, 3, 0, [20], 5),
     ("conv3 320>320 @64 B32 +resid +stats", 32, 64, 320, 0, 320, 3, 0x300, [20], 0),
-    ("conv3 640>320 cat @64 B32 +stats", 32, 64, 320, 320, 320, 3, 0x200, [20], 0),
     ("lin 640>640 @32 B32 +resid", 32, 32, 640, 0, 640, 1, 0x100, [20, 22], 0),
-    ("conv3 1280>1280 @16 B32 +stats", 32, 16, 1280, 0, 1280, 3, 0x200, [20], 0),
+    ("lin 640>640 @32 B32 +resid, A L2-RESIDENT", 32, 32, 640, 0, 640, 1, 0x100, [20], 4),
+    ("conv3 1280>1280 @16 B32 +stats", 32, 16, 1280, 0, 1280, 3, 0x200, [20, 23], 0),
     ("conv3 640>640 @32 B32 +stats", 32, 32, 640, 0, 640, 3, 0x200, [20], 0),
+    ("conv3 640>640 @32 B32 +stats, A L2-RESIDENT", 32, 32, 640, 0, 640, 3, 0x200, [20], 4),
 ]
 
 
