@@ -571,6 +571,41 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
       CD_PROBE_ONLY(pr_rows += probe_time() - pr_c1;)
       continue;
     }
+    // GEGLU (attention.py:37-44: value * gelu(gate)), the feed-forward input projection of every transformer block: the same
+    // block form. A 64-column chunk = [32 value | 32 gate] columns; 4 lanes cover a row's 32 outputs, 16 rows per pass.
+    if (geglu && cw == 64 && !p.out_f32 && !p.resid && !p.stats && !p.rowvec && (p.N & 63) == 0 && (p.out_ld & 7) == 0) {
+      constexpr int LD = T::EPI_LD;
+      bf16_t* const ocol = (bf16_t*)outp + (n / 64) * 32 + (n % 64);
+#pragma unroll
+      for (int rb = 0; rb < TM / 32; ++rb) {
+        const int mb = m0 + wm * TM + rb * 32;
+        if (mb < p.M) {
+          f32x4 vl[2], vh[2], gl[2], gh[2];
+#pragma unroll
+          for (int ps = 0; ps < 2; ++ps) {
+            const float* er = E + (rb * 32 + ps * 16 + vr) * LD + col;
+            vl[ps] = *(const f32x4*)er;        vh[ps] = *(const f32x4*)(er + 4);
+            gl[ps] = *(const f32x4*)(er + 32); gh[ps] = *(const f32x4*)(er + 36);
+          }
+#pragma unroll
+          for (int ps = 0; ps < 2; ++ps) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = (vl[ps][e] + bias_v[e]) * gelu_fast(gl[ps][e] + bias_g[e]);
+              v[4 + e] = (vh[ps][e] + bias_v[4 + e]) * gelu_fast(gh[ps][e] + bias_g[4 + e]);
+            }
+            const int m = mb + ps * 16 + vr;
+            if (m < p.M && n < p.N) {
+              CD_PROBE_ONLY(if (!(p.dbg & 1)))
+              *(uint4*)(ocol + (int64_t)m * p.out_ld) = pack8(v);
+            }
+          }
+        }
+      }
+      CD_PROBE_ONLY(pr_rows += probe_time() - pr_c1;)
+      continue;
+    }
     for (int r0 = 0; r0 < TM; r0 += rpp) {
       const int row = r0 + vr;
       const int m = m0 + wm * TM + row;
