@@ -94,7 +94,8 @@ __device__ __forceinline__ unsigned long long probe_realtime() {
 #endif
 
 template <int BM, int BN, int BK, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(64 * WM * WN) void k_conv_gemm(ConvGemmParams p) {
+// (4-wave workgroups with 32-deep K steps are the two-per-CU configurations: 2 waves per SIMD, so at most 256 registers)
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE == 3 && BM * BN >= 128 * 256) ? 2 : 1) void k_conv_gemm(ConvGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins below: the host pass only needs the launch stub
   using T = TileCfg<BM, BN, BK, WM, WN, NSTAGE>;
   constexpr int CPR = T::CPR, RPI = T::RPI, A_IPW = T::A_IPW, B_IPW = T::B_IPW, NW = T::NW;
@@ -789,6 +790,10 @@ const CfgInfo kCfgs[] = {
     {21, 128, 320, 160, "128x320 w2x2 s2"},
     {22, 256, 256, 128, "256x256 w4x2 s2"},
     {23, 128, 320, 160, "128x320 w4x2 s2"},
+    // two workgroups per CU (4 waves, 74 KB of LDS each, 32-deep K steps, 3-deep ring): one's prologue / epilogue runs under
+    // the other's K loop - for the short-K projections whose tiles spend a third of their time outside the K loop
+    {24, 128, 256, 128, "128x256 w2x2 s3 bk32 x2/CU"},
+    {25, 256, 128, 128, "256x128 w4x1 s3 bk32 x2/CU"},
 };
 inline bool cfg_needs_bk64(int id) { return id == 20 || id == 21 || id == 23; }
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -845,6 +850,8 @@ int dispatch(hipStream_t st, const ConvGemmParams& p, int id) {
         CD_CHECK(false, "conv_gemm: tile configuration %d needs channel counts that are multiples of 64", id);
       }
       return 0;
+    case 24: return launch_cfg<128, 256, 32, 2, 2, 3>(st, p);
+    case 25: return launch_cfg<256, 128, 32, 4, 1, 3>(st, p);
     default: CD_CHECK(false, "conv_gemm: unknown tile configuration %d", id);
   }
   return 0;
@@ -1003,10 +1010,13 @@ int tuned_config(hipStream_t st, const ConvGemmParams& p, bool k64) {
     if (p.act == ACT_GEGLU && (c.TN % 64) != 0) continue;
     if (c.BM >= 256 && p.M < 256) continue;
     if (cfg_needs_bk64(c.id) && !use64) continue;
+    if ((c.id == 24 || c.id == 25) && bi == 1) continue;  // one instantiation (32-deep K steps either way)
     if (c.BN == 320 && (p.N % 320) != 0) continue;
     const int64_t tiles = (int64_t)ceil_div(p.M, c.BM) * ceil_div(p.N, c.BN) * p.nbatch;
     if (split > 1) {
-      if (!sk.scratch || t128 >= 400 || nk < 4 * split || tiles * split > 2048) continue;
+      // a split only where THIS tile configuration leaves CUs idle (round 4: the wide tiles on the 16 x 16 level have 128
+      // tiles at B' = 32; their K loop is the fastest, two K ranges each fill the chip)
+      if (!sk.scratch || tiles >= 256 || nk < 4 * split || tiles * split > 2048) continue;
       if ((size_t)tiles * split * c.BM * c.BN * 4 > sk.scratch_bytes || tiles > sk.nflags) continue;
     }
     q.splitk = split; q.sk_scratch = sk.scratch; q.sk_flags = sk.flags;
