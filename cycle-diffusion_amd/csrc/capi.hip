@@ -320,8 +320,15 @@ int cd_net_missing_params(cd_handle h, int net, int* n_missing, char* first_name
 namespace {
 
 // ctx fp32 [B][L][Dc] -> bf16, optionally [uncond | cond] stacking for classifier-free guidance
-bf16_t* make_ctx(cd_engine* h, const float* a, const float* b, int B, int L, int Dc) {
+bf16_t* make_ctx(cd_engine* h, const float* a, const float* b, int B, int L, int Dc, bool f32 = false) {
   const int nb = b ? 2 * B : B;
+  if (f32) {  // fp32 networks (CD_PREC_F32 / F32X3 with transformer blocks) take the context as it is
+    float* out = (float*)h->arena.alloc((size_t)nb * L * Dc * 4);
+    const size_t half = (size_t)B * L * Dc;
+    HIP_CHECK(hipMemcpyAsync(out, a, half * 4, hipMemcpyDeviceToDevice, h->st));
+    if (b) HIP_CHECK(hipMemcpyAsync(out + half, b, half * 4, hipMemcpyDeviceToDevice, h->st));
+    return (bf16_t*)out;
+  }
   bf16_t* out = (bf16_t*)h->arena.alloc((size_t)nb * L * Dc * 2);
   launch_nchw_to_nhwc(h->st, a, out, B * L, Dc, 1, Dc, 1.f, 0.f, 0);
   if (b) launch_nchw_to_nhwc(h->st, b, out + (size_t)B * L * Dc, B * L, Dc, 1, Dc, 1.f, 0.f, 0);
@@ -388,14 +395,13 @@ SamplerState setup_sampler(cd_engine* h, int net, const float* ctx_c, const floa
   if (ctx_c || ctx_uc) {
     const int Dc = s.u->desc.context_dim;
     CD_CHECK(Dc > 0 && ctx_len > 0, "network has no cross-attention but a context was given");
-    bf16_t* cx = s.cfg ? make_ctx(h, ctx_uc, ctx_c, B, ctx_len, Dc) : make_ctx(h, gd.ctx_single, nullptr, B, ctx_len, Dc);
+    bf16_t* cx = s.cfg ? make_ctx(h, ctx_uc, ctx_c, B, ctx_len, Dc, s.u->f32) : make_ctx(h, gd.ctx_single, nullptr, B, ctx_len, Dc, s.u->f32);
     s.u->set_context(c, cx, s.Bn, ctx_len);
   } else {
     CD_CHECK(s.u->desc.context_dim <= 0 || !s.u->desc.use_spatial_transformer,
              "network expects a cross-attention context");
   }
   s.f32 = s.u->f32;
-  CD_CHECK(!(s.f32 && s.cfg), "CD_PREC_F32 networks are unconditional (no classifier-free guidance batch)");
   const size_t esz = s.f32 ? 4 : 2;
   s.xt = (float*)h->arena.alloc((size_t)B * s.C * s.HW * 4);
   s.xin = (bf16_t*)h->arena.alloc((size_t)s.Bn * s.HW * s.cpad * esz);
@@ -408,8 +414,12 @@ SamplerState setup_sampler(cd_engine* h, int net, const float* ctx_c, const floa
 
 void run_unet(cd_engine* h, SamplerState& s, int step) {
   Ctx c = h->ctx();
-  if (s.f32)
+  if (s.f32) {
     launch_nchw_to_nhwc_f32(h->st, s.xt, (float*)s.xin, s.B, s.C, s.HW, s.cpad, 1.f, 0.f, s.u->x3 ? 1 : 0, h->overflow_dev);
+    if (s.cfg)  // the classifier-free-guidance batch [uncond | cond] is built from one x_t (ddim.py:553-559)
+      launch_nchw_to_nhwc_f32(h->st, s.xt, (float*)s.xin + (size_t)s.B * s.HW * s.cpad, s.B, s.C, s.HW, s.cpad, 1.f, 0.f,
+                              s.u->x3 ? 1 : 0, h->overflow_dev);
+  }
   UNetIO io;
   io.xin = s.xin; io.B = s.Bn; io.tab = s.tab; io.step = step; io.t_shared = true;
   io.cfg_dup = s.cfg;
@@ -433,7 +443,7 @@ int cd_unet_forward(cd_handle h, int net, const float* x, const float* t, const 
   if (ctx) {
     const int Dc = u->desc.context_dim;
     CD_CHECK(Dc > 0, "network has no cross-attention");
-    bf16_t* cx = make_ctx(h, ctx, nullptr, B, ctx_len, Dc);
+    bf16_t* cx = make_ctx(h, ctx, nullptr, B, ctx_len, Dc, u->f32);
     u->set_context(c, cx, B, ctx_len);
   }
   bf16_t* xin = (bf16_t*)h->arena.alloc((size_t)B * HW * u->in_cpad * (u->f32 ? 4 : 2));

@@ -150,10 +150,15 @@ struct ConvOpts {
   // K = 320 linear kernel only - the caller checks conv_ln_fold_available() first
   bool ln_fold = false;
   float ln_eps = 1e-5f;
+  bool raw_geglu = false;      // fp32 path: a GEGLU projection leaves its [value | gate] columns as they are (k_geglu_f32 follows)
   bool want_stats = false;     // output feeds a GroupNorm: emit its statistics from the epilogue
   float* out_stats = nullptr;  // storage for them when `out` is preallocated
   int tile = 0;
 };
+// fp32 path, transformer blocks (st_f32.hip): q [B][Tq][ldq], k / v [B][Tk][ld] fp32 with per-image strides
+Act attention_flash_f32_fwd(Ctx& c, const float* q, int ldq, const float* k, int ldk, int64_t k_bs, const float* v, int ldv,
+                            int64_t v_bs, int B, int H, int Tq, int Tk, int D, float scale, int Himg, int Wimg, bool q_log2);
+Act geglu_f32_fwd(Ctx& c, const Act& h);  // [rows][2 * Nout] packed [32 value | 32 gate] blocks -> [rows][Nout]
 Act alloc_act(Ctx& c, int B, int H, int W, int C, bool with_stats = false);
 // y = conv(x [| x2]) with the fused epilogue; returns the output view (bf16 unless out_f32)
 Act conv_fwd(Ctx& c, const ConvW& w, const Act& x, const Act* x2, const ConvOpts& o);

@@ -235,7 +235,7 @@ Act alloc_act(Ctx& c, int B, int H, int W, int C, bool with_stats) {
 // CD_PREC_F32X3: x = [hi | lo] fp16 pairs (a GroupNorm output), weights [wh | wh | wl]: one 16-bit implicit GEMM
 // over the channel list [hi | lo | hi], fp32 bias / time-embedding row / residual / output (kernels.h kX3ActScale)
 static Act conv_split_fwd(Ctx& c, const ConvW& w, const Act& x, const ConvOpts& o) {
-  CD_CHECK(c.f32 && c.x3 && w.w3 && !w.geglu, "conv: split input outside the split-fp16 mode");
+  CD_CHECK(c.f32 && c.x3 && w.w3 && (!w.geglu || o.raw_geglu), "conv: split input outside the split-fp16 mode");
   CD_CHECK(x.C == w.Cpad && x.ld == 2 * x.C, "conv: split input of %d channels (ld %d) against Cpad %d", x.C, x.ld, w.Cpad);
   CD_CHECK(!o.ln_fold && (!o.resid || (o.resid->f32 && !o.resid->split)), "conv: split-mode operands");
   ConvGemmParams p;
@@ -306,8 +306,9 @@ Act conv_fwd(Ctx& c, const ConvW& w, const Act& x, const Act* x2, const ConvOpts
   p.wgt = w.w; p.wgt_frag = w.wfrag; p.Ktot = w.Ktot(); p.N = w.N;
   p.alpha = o.alpha; p.bias = w.b;
   p.rowvec = o.rowvec; p.rowvec_ld = o.rowvec_ld; p.rows_per_vec = o.rows_per_vec;
-  p.act = w.geglu ? ACT_GEGLU : o.act;
-  const int Nout = w.geglu ? w.N / 2 : w.N;
+  const bool fuse_geglu = w.geglu && !o.raw_geglu;
+  p.act = fuse_geglu ? ACT_GEGLU : o.act;
+  const int Nout = fuse_geglu ? w.N / 2 : w.N;
   Act y; y.B = x.B; y.H = p.Hout; y.W = p.Wout; y.C = Nout; y.f32 = c.f32;
   if (o.out) { y.p = (bf16_t*)o.out; y.ld = o.out_ld; }
   else {
@@ -410,8 +411,14 @@ Act attention_f32_fwd(Ctx& c, const Act& qk, const Act& v, int H, int D, float s
 }
 
 Act layernorm_fwd(Ctx& c, const LNW& w, const Act& x) {
-  CD_CHECK(!c.f32, "layernorm: the fp32 path covers the pixel-space U-Nets only (no transformer blocks)");
   CD_CHECK(x.C == w.C, "layernorm: channels");
+  if (c.f32) {  // fp32 rows; in the split mode the output is the fp16 pair the next three-term GEMM consumes
+    CD_CHECK(x.f32 && !x.split, "layernorm_f32: operand precision");
+    Act y = alloc_act(c, x.B, x.H, x.W, x.C);
+    if (c.x3) { y.split = true; y.ld = 2 * x.C; }  // same bytes as the fp32 tensor
+    launch_layernorm_f32(c.st, x.pf(), x.ld, y.pf(), x.rows(), x.C, w.g, w.b, 1e-5f, c.x3 ? 1 : 0, c.overflow);
+    return y;
+  }
   Act y = alloc_act(c, x.B, x.H, x.W, x.C);
   launch_layernorm(c.st, x.p, x.ld, y.p, y.ld, (int)x.rows(), x.C, w.g, w.b, 1e-5f);
   return y;
@@ -444,6 +451,22 @@ Act attention_vt_fwd(Ctx& c, const bf16_t* q, int ldq, const bf16_t* k, int ldk,
   p.scale = scale; p.q_log2 = q_log2 ? 1 : 0;
   launch_attention(c.st, p);
   return o;
+}
+
+Act attention_flash_f32_fwd(Ctx& c, const float* q, int ldq, const float* k, int ldk, int64_t k_bs, const float* v, int ldv,
+                            int64_t v_bs, int B, int H, int Tq, int Tk, int D, float scale, int Himg, int Wimg, bool q_log2) {
+  CD_CHECK(c.f32, "attention_flash_f32: fp32 path only");
+  Act o = alloc_act(c, B, Himg, Wimg, H * D);
+  launch_flash_f32(c.st, q, ldq, (int64_t)Tq * ldq, k, ldk, k_bs, v, ldv, v_bs, o.pf(), o.ld, (int64_t)Tq * o.ld, B, H, Tq,
+                   Tk, D, q_log2 ? 1.0f : scale * 1.44269504088896340736f);
+  return o;
+}
+
+Act geglu_f32_fwd(Ctx& c, const Act& h) {
+  CD_CHECK(c.f32 && h.f32 && !h.split && h.ld == h.C && (h.C % 64) == 0, "geglu_f32: operand");
+  Act y = alloc_act(c, h.B, h.H, h.W, h.C / 2);
+  launch_geglu_f32(c.st, h.pf(), y.pf(), h.rows(), h.C / 2);
+  return y;
 }
 
 }  // namespace cd

@@ -273,6 +273,15 @@ void launch_attention_f32(hipStream_t st, const float* q, int ldq, const float* 
 void launch_nchw_to_nhwc_f32(hipStream_t st, const float* x, float* y, int B, int C, int HW, int Cpad, float scale,
                              float shift, int split = 0, int* overflow = nullptr);
 void launch_avgpool2_f32(hipStream_t st, const float* x, float* y, int B, int H, int W, int C);
+// fp32 SpatialTransformer pieces (st_f32.hip): flash attention on fp32 MFMA (q, k, v token-major [B][T][ld] with the head
+// at column h * D; qmul multiplies q - scale * log2 e, or 1 when the to_q rows already carry it), LayerNorm (optionally
+// written as the split mode's fp16 pair), GEGLU on a materialised [rows][2 * Nout] projection in packed column order
+void launch_flash_f32(hipStream_t st, const float* q, int ldq, int64_t q_bs, const float* k, int ldk, int64_t k_bs,
+                      const float* v, int ldv, int64_t v_bs, float* o, int ldo, int64_t o_bs, int B, int H, int Tq, int Tk,
+                      int D, float qmul);
+void launch_layernorm_f32(hipStream_t st, const float* x, int ldx, float* y, int64_t rows, int C, const float* gamma,
+                          const float* beta, float eps, int split, int* overflow);
+void launch_geglu_f32(hipStream_t st, const float* h, float* y, int64_t rows, int Nout);
 void launch_upsample2_f32(hipStream_t st, const float* x, float* y, int B, int H, int W, int C);
 // Split-fp16 mode of the fp32 path (precision CD_PREC_F32X3): a GroupNorm-ed activation x is kept as the fp16 pair
 // T = [hi | lo] per pixel, hi = fp16(s_a x), lo = fp16(s_a x - hi), and a weight as [wh | wh | wl] per filter tap

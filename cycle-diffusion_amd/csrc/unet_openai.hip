@@ -197,7 +197,7 @@ UNetOpenAI::UNetOpenAI(const cd_net_desc& d) {
   f32 = d.precision == CD_PREC_F32 || d.precision == CD_PREC_F32X3;
   x3 = d.precision == CD_PREC_F32X3;
   params.f32 = f32; params.x3 = x3;
-  CD_CHECK(!(f32 && d.use_spatial_transformer), "CD_PREC_F32 covers U-Nets without SpatialTransformer blocks");
+
   mc_ = d.model_channels; hidden_ = 4 * mc_;
   image_size = d.image_size; out_channels = d.out_channels;
   in_cpad = round_up(d.in_channels, 32);
@@ -373,20 +373,24 @@ void UNetOpenAI::set_context(Ctx& c, const bf16_t* ctx, int B, int L) {
   if (B != ctx_B_ || L != ctx_L_) {
     for (void* p : ctx_allocs_) (void)hipFree(p);
     ctx_allocs_.clear();
+    const size_t esz = f32 ? 4 : 2;  // fp32 networks take the context as fp32 and keep fp32 K / V
     for (auto& s : st_) {
-      HIP_CHECK(hipMalloc((void**)&s.k2c, (size_t)B * L * s.C * 2 + 256));
-      HIP_CHECK(hipMalloc((void**)&s.v2c, (size_t)B * L * s.C * 2 + 256));
+      HIP_CHECK(hipMalloc((void**)&s.k2c, (size_t)B * L * s.C * esz + 256));
+      HIP_CHECK(hipMalloc((void**)&s.v2c, (size_t)B * L * s.C * esz + 256));
       ctx_allocs_.push_back(s.k2c); ctx_allocs_.push_back(s.v2c);
     }
     ctx_B_ = B; ctx_L_ = L;
   }
-  Act cx; cx.p = (bf16_t*)ctx; cx.B = 1; cx.H = B * L; cx.W = 1; cx.C = st_[0].ctx; cx.ld = cx.C;
+  const bool keep_f32 = c.f32, keep_x3 = c.x3;
+  c.f32 = f32; c.x3 = x3;  // (forward() sets these for its own duration; the context projections run outside it)
+  Act cx; cx.p = (bf16_t*)ctx; cx.B = 1; cx.H = B * L; cx.W = 1; cx.C = st_[0].ctx; cx.ld = cx.C; cx.f32 = f32;
   for (auto& s : st_) {
     ConvOpts o; o.pad = 0; o.out = s.k2c; o.out_ld = s.C;
     conv_fwd(c, *s.k2, cx, nullptr, o);
     o.out = s.v2c;
     conv_fwd(c, *s.v2, cx, nullptr, o);
   }
+  c.f32 = keep_f32; c.x3 = keep_x3;
 }
 
 // rows [0, n) of src -> rows [0, n) and [n, 2n) of dst (dense, `cols` 16-bit elements per row)
@@ -411,6 +415,58 @@ Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x_in, bool dup) {
   Act n = groupnorm_fwd(c, s.norm, x_in, nullptr, false);
   Act h = conv_fwd(c, *s.proj_in, n, nullptr, p0);  // tokens [B*T][C]
   const float scale = 1.0f / sqrtf((float)s.dh);
+  if (c.f32) {
+    // CD_PREC_F32 / F32X3 (st_f32.hip): the reference's own arithmetic for this block (`precision = "full"`,
+    // stable_diffusion_stochastic_text_wrapper.py:117). LayerNorm / GroupNorm outputs feed their projections as fp32 (k_conv_f32)
+    // or, in the split mode, as fp16 pairs (three-term products on the 16-bit matrix cores); the projections whose input is
+    // not normalised - to_out, ff.net.2, proj_out - stay on k_conv_f32; attention is fp32 flash attention.
+    CD_CHECK(!dup, "transformer block: prefix sharing is a 16-bit path feature");
+    const float* ck = (const float*)s.k2c;
+    const float* cv = (const float*)s.v2c;
+    {  // self-attention
+      const size_t m2 = c.arena->mark();
+      Act n1 = layernorm_fwd(c, s.ln1, h);
+      Act a;
+      if (s.qkv1) {
+        Act qkv = conv_fwd(c, *s.qkv1, n1, nullptr, p0);  // [B*T][3C] = q (log2 units) | k | v
+        a = attention_flash_f32_fwd(c, qkv.pf(), qkv.ld, qkv.pf() + C, qkv.ld, (int64_t)T * qkv.ld, qkv.pf() + 2 * C, qkv.ld,
+                                    (int64_t)T * qkv.ld, B, s.heads, T, T, s.dh, scale, x.H, x.W, /*q_log2=*/true);
+      } else {
+        Act qk = conv_fwd(c, *s.qk1, n1, nullptr, p0);  // [B*T][2C]
+        Act vv = conv_fwd(c, *s.v1, n1, nullptr, p0);   // [B*T][C]
+        a = attention_flash_f32_fwd(c, qk.pf(), qk.ld, qk.pf() + C, qk.ld, (int64_t)T * qk.ld, vv.pf(), vv.ld,
+                                    (int64_t)T * vv.ld, B, s.heads, T, T, s.dh, scale, x.H, x.W, /*q_log2=*/true);
+      }
+      ConvOpts o; o.pad = 0; o.resid = &h; o.out = h.p; o.out_ld = h.ld;  // in place: read then written by the same lane
+      conv_fwd(c, *s.o1, a, nullptr, o);
+      c.arena->release(m2);
+    }
+    {  // cross-attention over the cached fp32 context K / V
+      const size_t m2 = c.arena->mark();
+      Act n2 = layernorm_fwd(c, s.ln2, h);
+      Act q = conv_fwd(c, *s.q2, n2, nullptr, p0);
+      Act a = attention_flash_f32_fwd(c, q.pf(), q.ld, ck, C, (int64_t)ctx_L_ * C, cv, C, (int64_t)ctx_L_ * C, B, s.heads, T,
+                                      ctx_L_, s.dh, scale, x.H, x.W, /*q_log2=*/true);
+      ConvOpts o; o.pad = 0; o.resid = &h; o.out = h.p; o.out_ld = h.ld;
+      conv_fwd(c, *s.o2, a, nullptr, o);
+      c.arena->release(m2);
+    }
+    {  // GEGLU feed-forward: projection materialised, exact-erf GELU in fp32
+      const size_t m2 = c.arena->mark();
+      Act n3 = layernorm_fwd(c, s.ln3, h);
+      ConvOpts pg; pg.pad = 0; pg.raw_geglu = true;
+      Act g8 = conv_fwd(c, *s.ff1, n3, nullptr, pg);  // [B*T][8C] in packed [32 value | 32 gate] blocks
+      Act g = geglu_f32_fwd(c, g8);                   // [B*T][4C]
+      ConvOpts o; o.pad = 0; o.resid = &h; o.out = h.p; o.out_ld = h.ld;
+      conv_fwd(c, *s.ff2, g, nullptr, o);
+      c.arena->release(m2);
+    }
+    ConvOpts po; po.pad = 0; po.resid = &x; po.out = out.p; po.out_ld = out.ld; po.out_stats = out.stats_buf;
+    conv_fwd(c, *s.proj_out, h, nullptr, po);
+    if (c.x3 && out.stats_buf) out.stats = nullptr;  // proj_out runs on k_conv_f32 (raw input): no epilogue statistics
+    c.arena->release(mk);
+    return out;
+  }
   {  // self-attention
     const size_t m2 = c.arena->mark();
     Act n1 = layernorm_fwd(c, s.ln1, h);

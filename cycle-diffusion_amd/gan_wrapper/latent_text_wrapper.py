@@ -43,6 +43,9 @@ class StandInTextEmbedder:
         return torch.stack(out, 0)
 
 
+TEXT_PRECISIONS = {"fp16": _ffi.CD_PREC_16, "16": _ffi.CD_PREC_16, "fp32": _ffi.CD_PREC_F32, "fp32x3": _ffi.CD_PREC_F32X3}
+
+
 class _LatentStochasticTextWrapper(torch.nn.Module):
     # subclass constants
     UNET_DESC = None
@@ -56,8 +59,16 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
     def __init__(self, source_model_type, custom_steps, eta, white_box_steps, skip_steps,
                  encoder_unconditional_guidance_scales=None, decoder_unconditional_guidance_scales=None,
                  n_trials=None, cond_stage=None, ranker=None, device=None, text_encoder=None,
-                 noise_on_cpu=False, fold_ensemble=True, ranker_path=None):
+                 noise_on_cpu=False, fold_ensemble=True, ranker_path=None, precision="fp16"):
         super().__init__()
+        # `[gan] precision`: arithmetic of the U-Net (the first stage and the text towers stay 16-bit). 'fp16' (default):
+        # 16-bit storage, the benchmarked engine (55 dB against the reference on C2, 99-step self-cycle 2e-2 rms); 'fp32': the
+        # reference's own arithmetic (`precision = "full"`, stable_diffusion_stochastic_text_wrapper.py:117) - fp32 storage,
+        # fp32 matrix instructions, fp32 flash attention; 'fp32x3': the same network with every GroupNorm- / LayerNorm-fed
+        # convolution and projection as three-term split-fp16 products (include/cyclediff.h CD_PREC_F32X3)
+        if str(precision) not in TEXT_PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(TEXT_PRECISIONS))
+        self.precision = str(precision)
         self.encoder_unconditional_guidance_scales = encoder_unconditional_guidance_scales
         self.decoder_unconditional_guidance_scales = decoder_unconditional_guidance_scales
         self.n_trials = n_trials
@@ -70,6 +81,7 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
         self.noise_source = None
         self.engine = get_engine(device)
         udesc = self.UNET_DESC()
+        udesc.precision = TEXT_PRECISIONS[self.precision]
         self.channels, self.image_size = udesc.in_channels, udesc.image_size
         self.unet = self.engine.create_net(udesc)
         vdesc = self.VAE_DESC()

@@ -66,11 +66,14 @@ typedef struct cd_net_desc {
   int z_channels, embed_dim, double_z;
   /* Storage / arithmetic of the network: CD_PREC_16 = 16-bit activations and weights, fp32 accumulate (default);
    * CD_PREC_F32 = fp32 activations, weights and matrix instructions - what the reference itself computes in
-   * (`use_fp16=False`, improved_ddpm/script_util.py:15). U-Nets without SpatialTransformer blocks only: the
-   * pixel-space DDPMs of ddpm_ddim_wrapper.py, whose 'ddim' chain needs eps_hat at fp32 resolution;
-   * CD_PREC_F32X3 = the fp32 network with its GroupNorm-fed convolutions evaluated as three-term split-fp16 products on
-   * the 16-bit matrix cores (x = hi + lo, w = wh + wl; hi.wh + lo.wh + hi.wl, fp32 accumulate: 2^-22 per product
-   * instead of 2^-24; everything else as CD_PREC_F32). fp16 build of the library only. */
+   * (`use_fp16=False`, improved_ddpm/script_util.py:15; `precision = "full"`,
+   * stable_diffusion_stochastic_text_wrapper.py:117). U-Nets only: the pixel-space DDPMs of ddpm_ddim_wrapper.py, whose
+   * 'ddim' chain needs eps_hat at fp32 resolution, and - round 4 - the text-conditioned SD / LDM U-Nets
+   * (SpatialTransformer blocks with fp32 LayerNorm, fp32 flash attention and exact-erf GEGLU, csrc/st_f32.hip), for which
+   * it restores the encode -> decode cycle the 16-bit engine only closes to 2e-2;
+   * CD_PREC_F32X3 = the fp32 network with its GroupNorm- / LayerNorm-fed convolutions and projections evaluated as
+   * three-term split-fp16 products on the 16-bit matrix cores (x = hi + lo, w = wh + wl; hi.wh + lo.wh + hi.wl, fp32
+   * accumulate: 2^-22 per product instead of 2^-24; everything else as CD_PREC_F32). fp16 build of the library only. */
   int precision;
   /* VAE_KL only: > 0 selects the VQ first stage of the unconditional LDMs (VQModelInterface,
    * model/lib/latentdiff/ldm/models/autoencoder.py:264-282, `n_embed` codebook rows of width embed_dim): double_z = 0,

@@ -65,6 +65,32 @@ def test_sd_unet_forward_full_size_vs_oracle(engine, report, sd_unet):
     assert rmax < 8e-3 * FMT and rmean < 8e-3 * FMT, (rmax, rmean)
 
 
+@pytest.mark.parametrize("prec", [_ffi.CD_PREC_F32, _ffi.CD_PREC_F32X3], ids=["fp32", "fp32x3"])
+def test_sd_unet_forward_full_size_fp32_modes_vs_oracle(engine, report, prec):
+    """The same 860 M-parameter U-Net at `[gan] precision = fp32 / fp32x3`: fp32 flash attention over 4096 tokens at
+    d = 40 / 80 / 160, fp32 LayerNorm, GEGLU with the exact erf, the GroupNorm- / LayerNorm-fed projections as three-term
+    split products in the split mode. One sample, against the fp32 oracle (16-bit engine: 1.6e-3)."""
+    if prec == _ffi.CD_PREC_F32X3 and FMT != 1.0:
+        pytest.skip("the split mode needs the fp16 build")
+    d = cda.sd_v1_unet_desc()
+    d.precision = prec
+    net = engine.create_net(d)
+    sd = nets.synth_state_dict(engine.net_params(net), 0)
+    n, first = engine.load_state_dict(net, sd)
+    assert n == 0, first
+    cfg = nets.OpenAIUNetCfg(in_channels=4, out_channels=4, model_channels=320, num_res_blocks=2,
+                             channel_mult=(1, 2, 4, 4), attn_ds=(4, 2, 1), num_heads=8,
+                             use_spatial_transformer=True, context_dim=768)
+    x, c, _ = _inputs(1)
+    t = torch.tensor([981])
+    with torch.no_grad():
+        ref = nets.openai_unet(sd, cfg, x, t, c)
+    y = engine.unet_forward(net, x.cuda(), t.float().cuda(), c.cuda())
+    rmax, rmean = _rel(y, ref)
+    report.add("fullsize/sd_unet_" + ("fp32" if prec == _ffi.CD_PREC_F32 else "fp32x3"), rel_to_max=rmax, mean_rel=rmean)
+    assert rmax < 1e-4 and rmean < 1e-4, (rmax, rmean)
+
+
 def test_sd_unet_forward_batch16_streaming_linears_vs_oracle(engine, report, sd_unet):
     """The same U-Net at batch 16: the 64 x 64 level then has 65536 token rows, where the 320-channel linears run on
     the streaming kernel (csrc/lin_stream.hip) and norm2 / norm3 are folded into the cross-attention query and GEGLU

@@ -71,6 +71,25 @@ def test_unet_tiny_sd_vs_reference_fixture(engine, report):
     _check(report, "net/unet_tiny_sd", y, fx["y"])
 
 
+@pytest.mark.parametrize("prec", [_ffi.CD_PREC_F32, _ffi.CD_PREC_F32X3], ids=["fp32", "fp32x3"])
+def test_unet_tiny_sd_fp32_modes_vs_reference_fixture(engine, report, prec):
+    """The text-conditioned U-Net (ResBlocks + SpatialTransformer blocks, attention.py:152-261) in the reference's own
+    arithmetic - `precision = "full"`, stable_diffusion_stochastic_text_wrapper.py:117: fp32 storage, fp32 LayerNorm, fp32
+    flash attention (st_f32.hip), exact-erf GEGLU - and in its split-fp16 mode, against the same reference fixture as the
+    16-bit engine (whose bound is 8e-3)."""
+    if prec == _ffi.CD_PREC_F32X3 and FMT != 1.0:
+        pytest.skip("the split mode needs the fp16 build")
+    fx = gu.load("unet_tiny_sd")
+    d = tiny_sd_desc()
+    d.precision = prec
+    net, _ = _load(engine, d, fx)
+    x, t, ctx = gu.tiny_sd_inputs()
+    y = engine.unet_forward(net, x.cuda(), t.float().cuda(), ctx.cuda())
+    _check(report, "net/unet_tiny_sd_" + ("fp32" if prec == _ffi.CD_PREC_F32 else "fp32x3"), y, fx["y"], rel=5e-5, mean=5e-5)
+    y2 = engine.unet_forward(net, x.cuda(), t.float().cuda(), ctx.cuda())
+    assert torch.equal(y, y2)  # no tuner, no split-K on this path: bit-reproducible
+
+
 def test_unet_tiny_iddpm_vs_reference_fixture(engine, report):
     fx = gu.load("unet_tiny_iddpm")
     net, _ = _load(engine, tiny_iddpm_desc(), fx)
