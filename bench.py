@@ -237,7 +237,7 @@ def pmc_traffic_per_launch():
     FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over the U-Net forwards of one coalesced C2 launch set (B'=32
     encode, B'=64 CFG decode), which launch equally often. None when the summaries are absent."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for rnd in ("r3", "r2b"):  # the newest committed pair
+    for rnd in ("r4", "r3", "r2b"):  # the newest committed pair
         vals = []
         for b in (32, 64):
             try:
