@@ -159,15 +159,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
   // ---- per-lane staging geometry
   const int srow = lane / CPR;   // row within a glds instruction
   const int pchunk = lane % CPR; // physical 16-B chunk this lane fills
-  int a_iy0[A_IPW], a_ix0[A_IPW], a_boff[A_IPW], a_lc8[A_IPW];
-  unsigned a_voff[A_IPW];
+  // per staged row: a_yx = (iy0 << 16) | (ix0 & 0xffff), the input position of filter tap (0, 0); a_mk = validity of the KH
+  // tap rows (bits 0-7) and the KW tap columns (bits 8-15) at this output position | swizzled chunk << 16; a_boff = first
+  // pixel of the row's sample relative to the tile's first sample; a_base = byte offset of tap (0, 0) in the current source
+  // (channel-major order: a step's offset is a_base + a scalar tap displacement, or out of range where the masks say so)
+  int a_yx[A_IPW], a_boff[A_IPW];
+  unsigned a_mk[A_IPW], a_base[A_IPW], a_voff[A_IPW];
 #pragma unroll
   for (int i = 0; i < A_IPW; ++i) {
     const int row = (i * NW + wave) * RPI + srow;
     int m = m0 + row;
     CD_PROBE_ONLY(if (p.dbg & 4) m = (m0 & 0x3ff) + row;)  // timing experiment: every tile gathers A from the first images (L2-hot)
-    a_lc8[i] = (pchunk ^ ((row >> T::SWZ_SHIFT) & (CPR - 1))) * 8;
+    const int lc8 = (pchunk ^ ((row >> T::SWZ_SHIFT) & (CPR - 1))) * 8;
+    int iy0 = -32768, ix0 = 0;  // rows beyond M: always out of range -> zeros
     a_voff[i] = kInvalid;
+    a_base[i] = 0;
+    a_boff[i] = 0;
     if (m < p.M) {
       int b, oy, ox;
       if (pow2) {  // every layer of the reference networks: shifts instead of ~100-instruction divisions
@@ -179,14 +186,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
         const int rem = m - b * HWo;
         oy = rem / p.Wout; ox = rem - oy * p.Wout;
       }
-      a_iy0[i] = oy * p.stride - p.pad_t;
-      a_ix0[i] = ox * p.stride - p.pad_l;
+      iy0 = oy * p.stride - p.pad_t;
+      ix0 = ox * p.stride - p.pad_l;
       a_boff[i] = (b - b_first) * p.Hs * p.Ws;
-    } else {
-      a_iy0[i] = -(1 << 28);  // always out of range -> zeros
-      a_ix0[i] = 0;
-      a_boff[i] = 0;
     }
+    unsigned mk = (unsigned)(lc8 >> 3) << 16;
+    for (int r = 0; r < p.KH && r < 8; ++r) mk |= ((unsigned)(iy0 + r) < (unsigned)p.Hin ? 1u : 0u) << r;
+    for (int q = 0; q < p.KW && q < 8; ++q) mk |= ((unsigned)(ix0 + q) < (unsigned)p.Win ? 1u : 0u) << (8 + q);
+    a_mk[i] = mk;
+    a_yx[i] = (int)(((unsigned)iy0 << 16) | ((unsigned)ix0 & 0xffffu));
   }
   unsigned b_voff[B_IPW];
 #pragma unroll
@@ -207,14 +215,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
   const int kt1 = (kt0 + kper < nk) ? kt0 + kper : nk;
   // K-step cursor (uniform): tap (kr, kss) and channel offset kc within the concatenated channels
   int kr, kss, kc;
-  {
+  const int ntaps = p.KH * p.KW;
+  const bool chmajor = p.korder != 0 && ntaps > 1;  // K steps: the taps of one channel slice, then the next slice
+  if (chmajor) {
+    const int slice = kt0 / ntaps, tap = kt0 - slice * ntaps;
+    kc = slice * BK;
+    kr = tap / p.KW;
+    kss = tap - kr * p.KW;
+  } else {
     const int k_el = kt0 * BK;
     const int tap = k_el / Ctot;
     kc = k_el - tap * Ctot;
     kr = tap / p.KW;
     kss = tap - kr * p.KW;
   }
-  bool st_force = true;  // the first live tile of a split may start in the middle of a tap
+  bool st_force = true;  // the first live tile of a split may start in the middle of a tap / slice
 
   char* As = smem;                       // [NSTAGE][BM*BK*2]
   char* Bs = smem + NSTAGE * T::A_BYTES; // [NSTAGE][BN*BK*2]
@@ -229,27 +244,54 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
   auto prepare = [&](int kt) {
     st_live = kt < kt1;
     const int c_kc = kc, c_kr = kr, c_kss = kss;
-    kc += BK;
-    if (kc >= Ctot) {
-      kc = 0;
-      if (++kss >= p.KW) { kss = 0; ++kr; }
+    {  // cursor advance in select form (if / else stores to captured state end up as indexed stores to scratch)
+      const bool a_wk = c_kss + 1 >= p.KW;
+      const int a_kss = a_wk ? 0 : c_kss + 1;
+      const bool a_wr = a_wk && (c_kr + 1 >= p.KH);
+      const int a_kr = a_wr ? 0 : c_kr + (a_wk ? 1 : 0);
+      const int a_kc = c_kc + (a_wr ? BK : 0);
+      const bool b_wc = c_kc + BK >= Ctot;
+      const int b_kc = b_wc ? 0 : c_kc + BK;
+      const bool b_wk = b_wc && (c_kss + 1 >= p.KW);
+      const int b_kss = b_wk ? 0 : c_kss + (b_wc ? 1 : 0);
+      const int b_kr = c_kr + (b_wk ? 1 : 0);
+      kc = chmajor ? a_kc : b_kc;
+      kss = chmajor ? a_kss : b_kss;
+      kr = chmajor ? a_kr : b_kr;
     }
-    if (st_live && (c_kc == 0 || c_kc == p.C0 || st_force)) {  // new filter tap / second concat source
-      st_force = false;
-      const int ld = (c_kc < p.C0) ? p.ld0 : p.ld1;
+    const int ld = (c_kc < p.C0) ? p.ld0 : p.ld1;
+    if (st_live && chmajor && !p.up) {
+      // channel-major, no upsampling: the tap moves every step, by a displacement that is the same for every row
+      if (st_force || ((c_kr | c_kss) == 0 && (c_kc == 0 || c_kc == p.C0))) {  // first step in this source
+        st_force = false;
+#pragma unroll
+        for (int i = 0; i < A_IPW; ++i) {
+          const int iy0 = a_yx[i] >> 16, ix0 = (int)((unsigned)a_yx[i] << 16) >> 16;
+          const int pix = a_boff[i] + iy0 * p.Ws + ix0;  // may lie before the sample where the masks say invalid
+          a_base[i] = (unsigned)((pix * ld + (int)((a_mk[i] >> 16) << 3)) * 2);
+        }
+      }
+      const unsigned dt = (unsigned)((c_kr * p.Ws + c_kss) * ld * 2);
 #pragma unroll
       for (int i = 0; i < A_IPW; ++i) {
-        int iy = a_iy0[i] + c_kr, ix = a_ix0[i] + c_kss;
+        const unsigned ok = (a_mk[i] >> c_kr) & (a_mk[i] >> (8 + c_kss)) & 1u;
+        a_voff[i] = ok ? a_base[i] + dt : kInvalid;
+      }
+    } else if (st_live && (chmajor || c_kc == 0 || c_kc == p.C0 || st_force)) {  // new filter tap / second concat source
+      st_force = false;
+#pragma unroll
+      for (int i = 0; i < A_IPW; ++i) {
+        int iy = (a_yx[i] >> 16) + c_kr, ix = ((int)((unsigned)a_yx[i] << 16) >> 16) + c_kss;
         const bool ok = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);
         if (p.up) { iy >>= 1; ix >>= 1; }
         const int pix = a_boff[i] + iy * p.Ws + ix;
-        a_voff[i] = ok ? (unsigned)((pix * ld + a_lc8[i]) * 2) : kInvalid;
+        a_voff[i] = ok ? (unsigned)((pix * ld + (int)((a_mk[i] >> 16) << 3)) * 2) : kInvalid;
       }
     }
     const bool first = c_kc < p.C0;
     st_base = first ? base0 : base1;
     st_soffa = (first ? c_kc : c_kc - p.C0) * 2;
-    st_soffb = st_live ? kt * (BK * 2) : 0;
+    st_soffb = st_live ? (chmajor ? ((c_kr * p.KW + c_kss) * Ctot + c_kc) * 2 : kt * (BK * 2)) : 0;
   };
   auto issue = [&](int idx, int buf) {  // idx is a compile-time constant after unrolling
     if (idx < A_IPW) {
@@ -485,20 +527,28 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
     // 8-row pass on exposed LDS / L2 latency, and the statistics another 0.45 k on a 48-shuffle butterfly plus sixteen
     // 8-lane stores). GroupNorm statistics of the block: per-lane partial sums over the block's passes, transposed through
     // the LDS rows just consumed, column sums by the lane that owns the column -> two dense 256-byte stores.
-    const bool fast = !geglu && !p.out_f32 && !p.resid_f32 && p.act == ACT_NONE && (p.N & 7) == 0 && (p.out_ld & 7) == 0 &&
-                      (!p.resid || (p.resid_ld & 7) == 0) && (!p.rowvec || p.rows_per_vec >= p.M || (p.rows_per_vec & 31) == 0);
+    // (two flavours: 16-bit output with a 16-bit residual - the 16-bit engine - and fp32 output with an fp32 residual - the
+    // split mode of the fp32 path)
+    const bool f32o = p.out_f32 != 0;
+    const bool fast = !geglu && p.act == ACT_NONE && (p.N & 7) == 0 &&
+                      (!p.rowvec || p.rows_per_vec >= p.M || (p.rows_per_vec & 31) == 0) &&
+                      (f32o ? ((p.out_ld & 3) == 0 && (!p.resid || (p.resid_f32 && (p.resid_ld & 3) == 0)))
+                            : (!p.resid_f32 && (p.out_ld & 7) == 0 && (!p.resid || (p.resid_ld & 7) == 0)));
     if (fast) {
       constexpr int LD = T::EPI_LD;
       const int RPP = 64 / (cw / 8), NP = 32 / RPP;  // rows per pass, passes per 32-row block (compile-time: cw is)
       const bool colok = n < p.N;
       bf16_t* const ocol = (bf16_t*)outp + n;
+      float* const ocol32 = (float*)outp + n;
       const bf16_t* const rcol = p.resid ? p.resid + (int64_t)zb * p.o_bs + n : nullptr;
+      const float* const rcol32 = p.resid ? (const float*)p.resid + (int64_t)zb * p.o_bs + n : nullptr;
 #pragma unroll
       for (int rb = 0; rb < TM / 32; ++rb) {
         const int mb = m0 + wm * TM + rb * 32;  // first row of the block
         if (mb < p.M) {                         // (uniform) ragged M: whole blocks beyond the last row do nothing
           f32x4 lo[4], hi[4];
           uint4 rr[4];
+          f32x4 rlo[4], rhi[4];
           bool ok[4];
 #pragma unroll
           for (int ps = 0; ps < 4; ++ps)
@@ -513,7 +563,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
               const int m = mb + ps * RPP + vr;
               ok[ps] = colok && m < p.M;
               rr[ps] = (uint4){0u, 0u, 0u, 0u};
-              if (rcol && ok[ps]) rr[ps] = *(const uint4*)(rcol + (int64_t)m * p.resid_ld);
+              rlo[ps] = (f32x4){0.f, 0.f, 0.f, 0.f}; rhi[ps] = rlo[ps];
+              if (rcol && ok[ps]) {
+                if (f32o) {
+                  rlo[ps] = *(const f32x4*)(rcol32 + (int64_t)m * p.resid_ld);
+                  rhi[ps] = *(const f32x4*)(rcol32 + (int64_t)m * p.resid_ld + 4);
+                } else {
+                  rr[ps] = *(const uint4*)(rcol + (int64_t)m * p.resid_ld);
+                }
+              }
             }
           float add[8];
 #pragma unroll
@@ -532,11 +590,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
               unpack8(rr[ps], rf);
 #pragma unroll
               for (int e = 0; e < 4; ++e) { v[e] = lo[ps][e] + add[e]; v[4 + e] = hi[ps][e] + add[4 + e]; }
+              if (f32o) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += rf[e];
+                for (int e = 0; e < 4; ++e) { v[e] += rlo[ps][e]; v[4 + e] += rhi[ps][e]; }
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rf[e];
+              }
               if (ok[ps]) {
-                CD_PROBE_ONLY(if (!(p.dbg & 1)))
-                *(uint4*)(ocol + (int64_t)(mb + ps * RPP + vr) * p.out_ld) = pack8(v);
+                CD_PROBE_ONLY(if (!(p.dbg & 1))) {
+                  if (f32o) {
+                    float* op = ocol32 + (int64_t)(mb + ps * RPP + vr) * p.out_ld;
+                    *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                  } else {
+                    *(uint4*)(ocol + (int64_t)(mb + ps * RPP + vr) * p.out_ld) = pack8(v);
+                  }
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
               }
@@ -1081,6 +1151,8 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   id &= 0xff;
   if (pk.splitk > 1 && !pk.sk_scratch) { pk.sk_scratch = g_conv_splitk.scratch; pk.sk_flags = g_conv_splitk.flags; }
   pk.probe = g_conv_probe;
+  static const int korder_env = [] { const char* e = getenv("CYCLEDIFF_KORDER"); return e ? atoi(e) : -1; }();
+  if (korder_env >= 0) pk.korder = korder_env;
 #ifdef CD_PROBE
   if (const char* e = getenv("CYCLEDIFF_PROBE_DBG")) pk.dbg = atoi(e);
   if (pk.dbg & 2) pk.stats = nullptr;

@@ -158,7 +158,8 @@ struct ConvOpts {
 // fp32 path, transformer blocks (st_f32.hip): q [B][Tq][ldq], k / v [B][Tk][ld] fp32 with per-image strides
 Act attention_flash_f32_fwd(Ctx& c, const float* q, int ldq, const float* k, int ldk, int64_t k_bs, const float* v, int ldv,
                             int64_t v_bs, int B, int H, int Tq, int Tk, int D, float scale, int Himg, int Wimg, bool q_log2);
-Act geglu_f32_fwd(Ctx& c, const Act& h);  // [rows][2 * Nout] packed [32 value | 32 gate] blocks -> [rows][Nout]
+Act geglu_f32_fwd(Ctx& c, const Act& h);
+Act split_rows_f32_fwd(Ctx& c, const Act& x, const Act* x2 = nullptr);  // split mode: fp32 rows (or a channel concat) as fp16 pairs (range-guarded)  // [rows][2 * Nout] packed [32 value | 32 gate] blocks -> [rows][Nout]
 Act alloc_act(Ctx& c, int B, int H, int W, int C, bool with_stats = false);
 // y = conv(x [| x2]) with the fused epilogue; returns the output view (bf16 unless out_f32)
 Act conv_fwd(Ctx& c, const ConvW& w, const Act& x, const Act* x2, const ConvOpts& o);

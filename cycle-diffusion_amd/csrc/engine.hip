@@ -457,15 +457,29 @@ Act attention_flash_f32_fwd(Ctx& c, const float* q, int ldq, const float* k, int
                             int64_t v_bs, int B, int H, int Tq, int Tk, int D, float scale, int Himg, int Wimg, bool q_log2) {
   CD_CHECK(c.f32, "attention_flash_f32: fp32 path only");
   Act o = alloc_act(c, B, Himg, Wimg, H * D);
+  // split mode: the output feeds to_out as fp16 pairs (same bytes as the fp32 tensor; range guard as for the norms)
   launch_flash_f32(c.st, q, ldq, (int64_t)Tq * ldq, k, ldk, k_bs, v, ldv, v_bs, o.pf(), o.ld, (int64_t)Tq * o.ld, B, H, Tq,
-                   Tk, D, q_log2 ? 1.0f : scale * 1.44269504088896340736f);
+                   Tk, D, q_log2 ? 1.0f : scale * 1.44269504088896340736f, c.x3 ? 1 : 0, c.overflow);
+  if (c.x3) { o.split = true; o.ld = 2 * o.C; }
   return o;
 }
 
 Act geglu_f32_fwd(Ctx& c, const Act& h) {
   CD_CHECK(c.f32 && h.f32 && !h.split && h.ld == h.C && (h.C % 64) == 0, "geglu_f32: operand");
   Act y = alloc_act(c, h.B, h.H, h.W, h.C / 2);
-  launch_geglu_f32(c.st, h.pf(), y.pf(), h.rows(), h.C / 2);
+  launch_geglu_f32(c.st, h.pf(), y.pf(), h.rows(), h.C / 2, c.x3 ? 1 : 0, c.overflow);
+  if (c.x3) { y.split = true; y.ld = 2 * y.C; }
+  return y;
+}
+
+Act split_rows_f32_fwd(Ctx& c, const Act& x, const Act* x2) {
+  CD_CHECK(c.f32 && c.x3 && x.f32 && !x.split && (!x2 || (x2->f32 && !x2->split && x2->rows() == x.rows())),
+           "split_rows_f32: operand");
+  const int C = x.C + (x2 ? x2->C : 0);
+  Act y = alloc_act(c, x.B, x.H, x.W, C);
+  launch_split_rows_f32(c.st, x.pf(), x.ld, x.C, x2 ? x2->pf() : nullptr, x2 ? x2->ld : 4, x2 ? x2->C : 0, y.p, x.rows(),
+                        c.overflow);
+  y.split = true; y.ld = 2 * C;
   return y;
 }
 

@@ -95,6 +95,11 @@ struct ConvGemmParams {
   // phase-timing build only (-DCD_PROBE, lib/libcyclediff_probe.so; scripts/probe_report.py): every wave leaves
   // kProbeWords 64-bit words of s_memtime stamps here, [block][wave][kProbeWords]; null = off
   unsigned long long* probe = nullptr;
+  // order of the K steps of a KH x KW > 1 convolution: 1 (default) = channel-major - the KH * KW taps of one BK-channel
+  // slice, then the next slice: the re-reads of an activation line by neighbouring taps follow each other within KH * KW
+  // steps and hit the XCD's L2 (round 4: hit rate 54 -> 72 %, fabric fetch of the 320-channel 3 x 3 conv 750 -> 409 MB);
+  // 0 = tap-major (all channels of a tap, then the next tap; CYCLEDIFF_KORDER=0 for A/B runs)
+  int korder = 1;
   int dbg = 0;  // probe build: 1 = the epilogue skips its global stores, 2 = skips the statistics, 4 = every tile gathers
                 // its A rows from the first 1024 + BM rows (an L2-resident operand: what would the K loop do without misses?)
 };
@@ -278,10 +283,12 @@ void launch_avgpool2_f32(hipStream_t st, const float* x, float* y, int B, int H,
 // written as the split mode's fp16 pair), GEGLU on a materialised [rows][2 * Nout] projection in packed column order
 void launch_flash_f32(hipStream_t st, const float* q, int ldq, int64_t q_bs, const float* k, int ldk, int64_t k_bs,
                       const float* v, int ldv, int64_t v_bs, float* o, int ldo, int64_t o_bs, int B, int H, int Tq, int Tk,
-                      int D, float qmul);
+                      int D, float qmul, int split, int* overflow);
 void launch_layernorm_f32(hipStream_t st, const float* x, int ldx, float* y, int64_t rows, int C, const float* gamma,
                           const float* beta, float eps, int split, int* overflow);
-void launch_geglu_f32(hipStream_t st, const float* h, float* y, int64_t rows, int Nout);
+void launch_geglu_f32(hipStream_t st, const float* h, float* y, int64_t rows, int Nout, int split, int* overflow);
+void launch_split_rows_f32(hipStream_t st, const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, bf16_t* y,
+                           int64_t rows, int* overflow);
 void launch_upsample2_f32(hipStream_t st, const float* x, float* y, int B, int H, int W, int C);
 // Split-fp16 mode of the fp32 path (precision CD_PREC_F32X3): a GroupNorm-ed activation x is kept as the fp16 pair
 // T = [hi | lo] per pixel, hi = fp16(s_a x), lo = fp16(s_a x - hi), and a weight as [wh | wh | wl] per filter tap

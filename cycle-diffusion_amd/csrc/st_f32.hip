@@ -34,11 +34,13 @@ __device__ inline void split_pair(float v, _Float16& hi, _Float16& lo, int* over
 // accumulator layout holds them (key(s, half) = 8 (s / 4) + 4 half + s % 4) and the A operand reads V rows in the same
 // order from LDS, so P never moves between lanes.
 // q is expected in log2 units when q_log2 (scale * log2 e folded into the packed to_q rows, as on the 16-bit path).
-template <int DB>  // head width padded to DB blocks of 32
+// SPLIT: the output is written as the split mode's fp16 pair ([row][hi(C) | lo(C)], C = heads * D = ldo): the to_out
+// projection that follows is then a three-term product on the 16-bit matrix cores like the normalised ones.
+template <int DB, bool SPLIT>  // head width padded to DB blocks of 32
 __global__ __launch_bounds__(256) void k_flash_f32(const float* __restrict__ q, const float* __restrict__ k,
                                                    const float* __restrict__ v, float* __restrict__ o, int Tq, int Tk,
                                                    int D, int ldq, int ldk, int ldv, int ldo, int64_t q_bs, int64_t k_bs,
-                                                   int64_t v_bs, int64_t o_bs, float qmul) {
+                                                   int64_t v_bs, int64_t o_bs, float qmul, int* overflow) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int DP = 32 * DB, LDK = DP + 1, KT = 32;
   __shared__ float Ks[KT * LDK];
@@ -129,13 +131,28 @@ __global__ __launch_bounds__(256) void k_flash_f32(const float* __restrict__ q, 
   const int qi = q0 + col;
   if (qi < Tq) {
     float* orow = o + (int64_t)b * o_bs + (int64_t)qi * ldo + h * D;
+    _Float16* hrow = (_Float16*)o + 2 * ((int64_t)b * o_bs + (int64_t)qi * ldo) + h * D;  // split form: row of 2 * ldo halves
 #pragma unroll
     for (int j = 0; j < DB; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = 32 * j + 8 * g + 4 * half;  // 4 consecutive head dims: accumulator registers 4 g .. 4 g + 3
-        if (d < D) *(f4*)(orow + d) = (f4){oacc[j][4 * g] * inv, oacc[j][4 * g + 1] * inv, oacc[j][4 * g + 2] * inv,
-                                          oacc[j][4 * g + 3] * inv};
+        if (d < D) {
+          const f4 val = {oacc[j][4 * g] * inv, oacc[j][4 * g + 1] * inv, oacc[j][4 * g + 2] * inv, oacc[j][4 * g + 3] * inv};
+          if (SPLIT) {
+            h4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              _Float16 a_, b_;
+              split_pair(val[e] * kX3ActScale, a_, b_, overflow);
+              hi[e] = a_; lo[e] = b_;
+            }
+            *(h4*)(hrow + d) = hi;
+            *(h4*)(hrow + ldo + d) = lo;
+          } else {
+            *(f4*)(orow + d) = val;
+          }
+        }
       }
   }
 #endif
@@ -206,7 +223,8 @@ __global__ __launch_bounds__(256) void k_layernorm_f32(const float* __restrict__
 // ---------------------------------------------------------------------------------------- GEGLU
 // h [rows][2 * Nout]: the GEGLU projection (attention.py:37-44) in the packed column order of its weights - blocks of 64 =
 // [32 value | 32 gate] columns (k_pack_rows). y [rows][Nout] = value * gelu(gate), exact erf form (F.gelu default).
-__global__ void k_geglu_f32(const float* __restrict__ h, float* __restrict__ y, int64_t rows, int Nout) {
+template <bool SPLIT>
+__global__ void k_geglu_f32(const float* __restrict__ h, float* __restrict__ y, int64_t rows, int Nout, int* overflow) {
   const int n4 = Nout >> 2;
   const int64_t total = rows * n4;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -218,7 +236,42 @@ __global__ void k_geglu_f32(const float* __restrict__ h, float* __restrict__ y, 
     f4 out;
 #pragma unroll
     for (int e = 0; e < 4; ++e) out[e] = val[e] * (0.5f * gate[e] * (1.0f + erff(gate[e] * 0.70710678118654752440f)));
-    *(f4*)(y + r * Nout + c) = out;
+    if (SPLIT) {
+      h4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        _Float16 a_, b_;
+        split_pair(out[e] * kX3ActScale, a_, b_, overflow);
+        hi[e] = a_; lo[e] = b_;
+      }
+      _Float16* yr = (_Float16*)y + r * (2 * (int64_t)Nout);
+      *(h4*)(yr + c) = hi;
+      *(h4*)(yr + Nout + c) = lo;
+    } else {
+      *(f4*)(y + r * Nout + c) = out;
+    }
+  }
+}
+
+// fp32 rows (optionally the channel concat of two tensors) -> the split mode's fp16 pairs [row][hi(C) | lo(C)], C = C0 + C1:
+// the residual stream ahead of proj_out, the inputs of the 1 x 1 skip projections (th.cat([h, hs.pop()]), openaimodel.py:736)
+__global__ void k_split_rows_f32(const float* __restrict__ x0, int ld0, int C0, const float* __restrict__ x1, int ld1, int C1,
+                                 _Float16* __restrict__ y, int64_t rows, int* overflow) {
+  const int C = C0 + C1, n4 = C >> 2;
+  const int64_t total = rows * n4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % n4) * 4;
+    const int64_t r = i / n4;
+    const f4 v = c < C0 ? *(const f4*)(x0 + r * ld0 + c) : *(const f4*)(x1 + r * ld1 + (c - C0));
+    h4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 a_, b_;
+      split_pair(v[e] * kX3ActScale, a_, b_, overflow);
+      hi[e] = a_; lo[e] = b_;
+    }
+    *(h4*)(y + r * (2 * (int64_t)C) + c) = hi;
+    *(h4*)(y + r * (2 * (int64_t)C) + C + c) = lo;
   }
 }
 
@@ -227,12 +280,19 @@ using namespace st_f32_detail;
 
 void launch_flash_f32(hipStream_t st, const float* q, int ldq, int64_t q_bs, const float* k, int ldk, int64_t k_bs,
                       const float* v, int ldv, int64_t v_bs, float* o, int ldo, int64_t o_bs, int B, int H, int Tq, int Tk,
-                      int D, float qmul) {
+                      int D, float qmul, int split, int* overflow) {
   CD_CHECK(D % 4 == 0 && D <= 160 && (ldq % 4) == 0 && (ldk % 4) == 0 && (ldv % 4) == 0 && (ldo % 4) == 0 && Tq > 0 && Tk > 0,
            "flash_f32: D=%d ld %d %d %d %d", D, ldq, ldk, ldv, ldo);
   const dim3 grid((Tq + 127) / 128, H, B), block(256);
   const int DB = (D + 31) / 32;
-#define CD_FLASH(N) hipLaunchKernelGGL((k_flash_f32<N>), grid, block, 0, st, q, k, v, o, Tq, Tk, D, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, qmul)
+  CD_CHECK(!split || ldo == H * D, "flash_f32: the split output is a dense [rows][2 * heads * D] tensor");
+#define CD_FLASH(N)                                                                                                        \
+  do {                                                                                                                     \
+    if (split) hipLaunchKernelGGL((k_flash_f32<N, true>), grid, block, 0, st, q, k, v, o, Tq, Tk, D, ldq, ldk, ldv, ldo,  \
+                                  q_bs, k_bs, v_bs, o_bs, qmul, overflow);                                                \
+    else hipLaunchKernelGGL((k_flash_f32<N, false>), grid, block, 0, st, q, k, v, o, Tq, Tk, D, ldq, ldk, ldv, ldo, q_bs, \
+                            k_bs, v_bs, o_bs, qmul, overflow);                                                            \
+  } while (0)
   switch (DB) {
     case 1: CD_FLASH(1); break;
     case 2: CD_FLASH(2); break;
@@ -253,12 +313,23 @@ void launch_layernorm_f32(hipStream_t st, const float* x, int ldx, float* y, int
     hipLaunchKernelGGL((k_layernorm_f32<false>), dim3(grid), dim3(256), 0, st, x, ldx, y, rows, C, gamma, beta, eps, overflow);
 }
 
-void launch_geglu_f32(hipStream_t st, const float* h, float* y, int64_t rows, int Nout) {
+void launch_geglu_f32(hipStream_t st, const float* h, float* y, int64_t rows, int Nout, int split, int* overflow) {
   CD_CHECK(Nout % 32 == 0, "geglu_f32: Nout=%d", Nout);
   const int64_t n = rows * (Nout / 4);
   int64_t g = (n + 255) / 256;
   if (g > 8192) g = 8192;
-  hipLaunchKernelGGL(k_geglu_f32, dim3((unsigned)g), dim3(256), 0, st, h, y, rows, Nout);
+  if (split) hipLaunchKernelGGL(k_geglu_f32<true>, dim3((unsigned)g), dim3(256), 0, st, h, y, rows, Nout, overflow);
+  else hipLaunchKernelGGL(k_geglu_f32<false>, dim3((unsigned)g), dim3(256), 0, st, h, y, rows, Nout, overflow);
+}
+
+void launch_split_rows_f32(hipStream_t st, const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, bf16_t* y,
+                           int64_t rows, int* overflow) {
+  CD_CHECK(C0 % 4 == 0 && C1 % 4 == 0 && (ld0 % 4) == 0 && (ld1 % 4) == 0, "split_rows_f32: C=%d+%d", C0, C1);
+  const int64_t n = rows * ((C0 + C1) / 4);
+  int64_t g = (n + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(k_split_rows_f32, dim3((unsigned)g), dim3(256), 0, st, x0, ld0, C0, x1, ld1, C1, (_Float16*)y, rows,
+                     overflow);
 }
 
 }  // namespace cd

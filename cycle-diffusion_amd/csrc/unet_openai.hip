@@ -343,6 +343,10 @@ Act UNetOpenAI::res_fwd(Ctx& c, const ResW& r, const Act& x, const Act* x2, cons
   Act skip;
   if (r.skip) {
     ConvOpts os; os.pad = 0;
+    // (Round 4 measured the split form of this projection - its unnormalised input, or the concat of two, first written as
+    // fp16 pairs by split_rows_f32_fwd: on config 5 the conversion pass over the 256 x 256 tensors costs more than k_conv_f32
+    // saves - 2.93 -> 2.82 images/s same box, profiles/r4_c5r_split_skip_projection_ab.txt - so it stays on the fp32 matrix
+    // instructions.)
     skip = conv_fwd(c, *r.skip, xs, xs2, os);
   } else {
     CD_CHECK(!xs2, "identity skip with concat input");
@@ -418,8 +422,9 @@ Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x_in, bool dup) {
   if (c.f32) {
     // CD_PREC_F32 / F32X3 (st_f32.hip): the reference's own arithmetic for this block (`precision = "full"`,
     // stable_diffusion_stochastic_text_wrapper.py:117). LayerNorm / GroupNorm outputs feed their projections as fp32 (k_conv_f32)
-    // or, in the split mode, as fp16 pairs (three-term products on the 16-bit matrix cores); the projections whose input is
-    // not normalised - to_out, ff.net.2, proj_out - stay on k_conv_f32; attention is fp32 flash attention.
+    // or, in the split mode, as fp16 pairs (three-term products on the 16-bit matrix cores) - there the attention output, the
+    // GEGLU output and the residual stream ahead of proj_out are written as pairs too (range-guarded like the norms: a value
+    // beyond 4094 raises at the next API entry, and `precision = fp32` is the answer); attention is fp32 flash attention.
     CD_CHECK(!dup, "transformer block: prefix sharing is a 16-bit path feature");
     const float* ck = (const float*)s.k2c;
     const float* cv = (const float*)s.v2c;
@@ -462,8 +467,13 @@ Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x_in, bool dup) {
       c.arena->release(m2);
     }
     ConvOpts po; po.pad = 0; po.resid = &x; po.out = out.p; po.out_ld = out.ld; po.out_stats = out.stats_buf;
-    conv_fwd(c, *s.proj_out, h, nullptr, po);
-    if (c.x3 && out.stats_buf) out.stats = nullptr;  // proj_out runs on k_conv_f32 (raw input): no epilogue statistics
+    if (c.x3) {  // the residual stream as fp16 pairs: proj_out is a split product too, and its epilogue emits the statistics
+      Act hs = split_rows_f32_fwd(c, h);
+      Act y = conv_fwd(c, *s.proj_out, hs, nullptr, po);
+      out.stats = y.stats;
+    } else {
+      conv_fwd(c, *s.proj_out, h, nullptr, po);
+    }
     c.arena->release(mk);
     return out;
   }
