@@ -216,7 +216,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
   // K-step cursor (uniform): tap (kr, kss) and channel offset kc within the concatenated channels
   int kr, kss, kc;
   const int ntaps = p.KH * p.KW;
-  const bool chmajor = p.korder != 0 && ntaps > 1;  // K steps: the taps of one channel slice, then the next slice
+  // K steps: the taps of one channel slice, then the next slice (the per-row tap masks hold 8 rows x 8 columns: the patch
+  // embedding convs of the CLIP vision tower - 16 x 16 / 32 x 32 taps, stride = patch - keep the tap-major order)
+  const bool chmajor = p.korder != 0 && ntaps > 1 && p.KH <= 8 && p.KW <= 8;
   if (chmajor) {
     const int slice = kt0 / ntaps, tap = kt0 - slice * ntaps;
     kc = slice * BK;

@@ -98,6 +98,10 @@ CONV_CASES = [
     ("3x3_N192_t22_masked", 2, 64, 0, 16, 16, 192, 3, 1, 1, False, False, True, False, False, 0, 22),
     ("3x3_1280_8x8_t20_split4", 2, 1280, 0, 8, 8, 1280, 3, 1, 1, False, False, True, True, True, 0, 20 | (4 << 8)),
     ("3x3_up_640_t23", 1, 640, 0, 8, 8, 640, 3, 1, 1, False, True, True, False, False, 0, 23),
+    # a patch-embedding conv (CLIP vision tower: kernel = stride = patch): 256 taps - more than the 8 x 8 tap masks of the
+    # channel-major K order hold, so it must take the tap-major order (round 4: the first mask version broke this layer)
+    ("16x16_patch_stride16", 2, 32, 0, 64, 64, 96, 16, 16, 0, False, False, True, False, False, 0, 0),
+    ("5x5_pad2", 1, 64, 0, 12, 12, 64, 5, 1, 2, False, False, True, False, False, 0, 0),
     # split-K (tile | split << 8): K ranges that start mid-tap / in the second concat source, ragged M,
     # more splits than K steps (empty ranges), fused epilogue after the fix-up
     ("3x3_1280_8x8_split4", 2, 1280, 0, 8, 8, 1280, 3, 1, 1, False, False, True, True, True, 0, 8 | (4 << 8)),
