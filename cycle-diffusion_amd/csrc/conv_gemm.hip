@@ -93,7 +93,8 @@ __device__ __forceinline__ unsigned long long probe_realtime() {
 #define CD_PROBE_ONLY(...)
 #endif
 
-template <int BM, int BN, int BK, int WM, int WN, int NSTAGE>
+// CHM: channel-major K order (compile-time: the tap-major instantiation carries none of its state)
+template <int BM, int BN, int BK, int WM, int WN, int NSTAGE, bool CHM = false>
 // (4-wave workgroups with 32-deep K steps are the two-per-CU configurations: 2 waves per SIMD, so at most 256 registers)
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE == 3 && BM * BN >= 128 * 256) ? 2 : 1) void k_conv_gemm(ConvGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins below: the host pass only needs the launch stub
@@ -159,22 +160,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
   // ---- per-lane staging geometry
   const int srow = lane / CPR;   // row within a glds instruction
   const int pchunk = lane % CPR; // physical 16-B chunk this lane fills
-  // per staged row: a_yx = (iy0 << 16) | (ix0 & 0xffff), the input position of filter tap (0, 0); a_mk = validity of the KH
-  // tap rows (bits 0-7) and the KW tap columns (bits 8-15) at this output position | swizzled chunk << 16; a_boff = first
-  // pixel of the row's sample relative to the tile's first sample; a_base = byte offset of tap (0, 0) in the current source
-  // (channel-major order: a step's offset is a_base + a scalar tap displacement, or out of range where the masks say so)
-  int a_yx[A_IPW], a_boff[A_IPW];
-  unsigned a_mk[A_IPW], a_base[A_IPW], a_voff[A_IPW];
+  int a_iy0[A_IPW], a_ix0[A_IPW], a_boff[A_IPW], a_lc8[A_IPW];
+  unsigned a_voff[A_IPW];
+  // channel-major order (CHM): a_mk = validity of the KH tap rows (bits 0-7) and KW tap columns (bits 8-15) at this output
+  // position; a_base = byte offset of tap (0, 0) in the current source - a step's offset is a_base + a scalar tap
+  // displacement, or out of range where the masks say so (a_iy0 / a_ix0 / a_lc8 are then dead after the first K step)
+  unsigned a_mk[A_IPW], a_base[A_IPW];
 #pragma unroll
   for (int i = 0; i < A_IPW; ++i) {
     const int row = (i * NW + wave) * RPI + srow;
     int m = m0 + row;
     CD_PROBE_ONLY(if (p.dbg & 4) m = (m0 & 0x3ff) + row;)  // timing experiment: every tile gathers A from the first images (L2-hot)
-    const int lc8 = (pchunk ^ ((row >> T::SWZ_SHIFT) & (CPR - 1))) * 8;
-    int iy0 = -32768, ix0 = 0;  // rows beyond M: always out of range -> zeros
+    a_lc8[i] = (pchunk ^ ((row >> T::SWZ_SHIFT) & (CPR - 1))) * 8;
     a_voff[i] = kInvalid;
-    a_base[i] = 0;
-    a_boff[i] = 0;
+    a_mk[i] = 0; a_base[i] = 0;
     if (m < p.M) {
       int b, oy, ox;
       if (pow2) {  // every layer of the reference networks: shifts instead of ~100-instruction divisions
@@ -186,15 +185,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
         const int rem = m - b * HWo;
         oy = rem / p.Wout; ox = rem - oy * p.Wout;
       }
-      iy0 = oy * p.stride - p.pad_t;
-      ix0 = ox * p.stride - p.pad_l;
+      a_iy0[i] = oy * p.stride - p.pad_t;
+      a_ix0[i] = ox * p.stride - p.pad_l;
       a_boff[i] = (b - b_first) * p.Hs * p.Ws;
+    } else {
+      a_iy0[i] = -(1 << 28);  // always out of range -> zeros
+      a_ix0[i] = 0;
+      a_boff[i] = 0;
     }
-    unsigned mk = (unsigned)(lc8 >> 3) << 16;
-    for (int r = 0; r < p.KH && r < 8; ++r) mk |= ((unsigned)(iy0 + r) < (unsigned)p.Hin ? 1u : 0u) << r;
-    for (int q = 0; q < p.KW && q < 8; ++q) mk |= ((unsigned)(ix0 + q) < (unsigned)p.Win ? 1u : 0u) << (8 + q);
-    a_mk[i] = mk;
-    a_yx[i] = (int)(((unsigned)iy0 << 16) | ((unsigned)ix0 & 0xffffu));
+    if constexpr (CHM) {
+      unsigned mk = 0;
+      for (int r = 0; r < p.KH; ++r) mk |= ((unsigned)(a_iy0[i] + r) < (unsigned)p.Hin ? 1u : 0u) << r;
+      for (int q = 0; q < p.KW; ++q) mk |= ((unsigned)(a_ix0[i] + q) < (unsigned)p.Win ? 1u : 0u) << (8 + q);
+      a_mk[i] = mk;
+    }
   }
   unsigned b_voff[B_IPW];
 #pragma unroll
@@ -215,11 +219,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
   const int kt1 = (kt0 + kper < nk) ? kt0 + kper : nk;
   // K-step cursor (uniform): tap (kr, kss) and channel offset kc within the concatenated channels
   int kr, kss, kc;
-  const int ntaps = p.KH * p.KW;
-  // K steps: the taps of one channel slice, then the next slice (the per-row tap masks hold 8 rows x 8 columns: the patch
-  // embedding convs of the CLIP vision tower - 16 x 16 / 32 x 32 taps, stride = patch - keep the tap-major order)
-  const bool chmajor = p.korder != 0 && ntaps > 1 && p.KH <= 8 && p.KW <= 8;
-  if (chmajor) {
+  if constexpr (CHM) {  // step kt = (channel slice kt / ntaps, tap kt % ntaps)
+    const int ntaps = p.KH * p.KW;
     const int slice = kt0 / ntaps, tap = kt0 - slice * ntaps;
     kc = slice * BK;
     kr = tap / p.KW;
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
     kr = tap / p.KW;
     kss = tap - kr * p.KW;
   }
-  bool st_force = true;  // the first live tile of a split may start in the middle of a tap / slice
+  bool st_force = true;  // the first live tile of a split may start in the middle of a tap
 
   char* As = smem;                       // [NSTAGE][BM*BK*2]
   char* Bs = smem + NSTAGE * T::A_BYTES; // [NSTAGE][BN*BK*2]
@@ -246,54 +247,54 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
   auto prepare = [&](int kt) {
     st_live = kt < kt1;
     const int c_kc = kc, c_kr = kr, c_kss = kss;
-    {  // cursor advance in select form (if / else stores to captured state end up as indexed stores to scratch)
-      const bool a_wk = c_kss + 1 >= p.KW;
-      const int a_kss = a_wk ? 0 : c_kss + 1;
-      const bool a_wr = a_wk && (c_kr + 1 >= p.KH);
-      const int a_kr = a_wr ? 0 : c_kr + (a_wk ? 1 : 0);
-      const int a_kc = c_kc + (a_wr ? BK : 0);
-      const bool b_wc = c_kc + BK >= Ctot;
-      const int b_kc = b_wc ? 0 : c_kc + BK;
-      const bool b_wk = b_wc && (c_kss + 1 >= p.KW);
-      const int b_kss = b_wk ? 0 : c_kss + (b_wc ? 1 : 0);
-      const int b_kr = c_kr + (b_wk ? 1 : 0);
-      kc = chmajor ? a_kc : b_kc;
-      kss = chmajor ? a_kss : b_kss;
-      kr = chmajor ? a_kr : b_kr;
-    }
-    const int ld = (c_kc < p.C0) ? p.ld0 : p.ld1;
-    if (st_live && chmajor && !p.up) {
-      // channel-major, no upsampling: the tap moves every step, by a displacement that is the same for every row
-      if (st_force || ((c_kr | c_kss) == 0 && (c_kc == 0 || c_kc == p.C0))) {  // first step in this source
-        st_force = false;
+    if constexpr (CHM) {
+      // channel-major (no upsampling: the launcher keeps those tap-major): the tap moves every step, by a displacement that
+      // is the same for every row; cursor advance in select form (if / else stores to captured state end up in scratch)
+      const bool wk = c_kss + 1 >= p.KW;
+      const bool wr = wk && (c_kr + 1 >= p.KH);
+      kss = wk ? 0 : c_kss + 1;
+      kr = wr ? 0 : c_kr + (wk ? 1 : 0);
+      kc = c_kc + (wr ? BK : 0);
+      if (st_live) {
+        const int ld = (c_kc < p.C0) ? p.ld0 : p.ld1;
+        if (st_force || ((c_kr | c_kss) == 0 && (c_kc == 0 || c_kc == p.C0))) {  // first step in this source
+          st_force = false;
+#pragma unroll
+          for (int i = 0; i < A_IPW; ++i) {
+            const int pix = a_boff[i] + a_iy0[i] * p.Ws + a_ix0[i];  // may lie before the sample where the masks say invalid
+            a_base[i] = (unsigned)((pix * ld + a_lc8[i]) * 2);
+          }
+        }
+        const unsigned dt = (unsigned)((c_kr * p.Ws + c_kss) * ld * 2);
 #pragma unroll
         for (int i = 0; i < A_IPW; ++i) {
-          const int iy0 = a_yx[i] >> 16, ix0 = (int)((unsigned)a_yx[i] << 16) >> 16;
-          const int pix = a_boff[i] + iy0 * p.Ws + ix0;  // may lie before the sample where the masks say invalid
-          a_base[i] = (unsigned)((pix * ld + (int)((a_mk[i] >> 16) << 3)) * 2);
+          const unsigned ok = (a_mk[i] >> c_kr) & (a_mk[i] >> (8 + c_kss)) & 1u;
+          a_voff[i] = ok ? a_base[i] + dt : kInvalid;
         }
       }
-      const unsigned dt = (unsigned)((c_kr * p.Ws + c_kss) * ld * 2);
-#pragma unroll
-      for (int i = 0; i < A_IPW; ++i) {
-        const unsigned ok = (a_mk[i] >> c_kr) & (a_mk[i] >> (8 + c_kss)) & 1u;
-        a_voff[i] = ok ? a_base[i] + dt : kInvalid;
+    } else {
+      kc += BK;
+      if (kc >= Ctot) {
+        kc = 0;
+        if (++kss >= p.KW) { kss = 0; ++kr; }
       }
-    } else if (st_live && (chmajor || c_kc == 0 || c_kc == p.C0 || st_force)) {  // new filter tap / second concat source
-      st_force = false;
+      if (st_live && (c_kc == 0 || c_kc == p.C0 || st_force)) {  // new filter tap / second concat source
+        st_force = false;
+        const int ld = (c_kc < p.C0) ? p.ld0 : p.ld1;
 #pragma unroll
-      for (int i = 0; i < A_IPW; ++i) {
-        int iy = (a_yx[i] >> 16) + c_kr, ix = ((int)((unsigned)a_yx[i] << 16) >> 16) + c_kss;
-        const bool ok = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);
-        if (p.up) { iy >>= 1; ix >>= 1; }
-        const int pix = a_boff[i] + iy * p.Ws + ix;
-        a_voff[i] = ok ? (unsigned)((pix * ld + (int)((a_mk[i] >> 16) << 3)) * 2) : kInvalid;
+        for (int i = 0; i < A_IPW; ++i) {
+          int iy = a_iy0[i] + c_kr, ix = a_ix0[i] + c_kss;
+          const bool ok = ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);
+          if (p.up) { iy >>= 1; ix >>= 1; }
+          const int pix = a_boff[i] + iy * p.Ws + ix;
+          a_voff[i] = ok ? (unsigned)((pix * ld + a_lc8[i]) * 2) : kInvalid;
+        }
       }
     }
     const bool first = c_kc < p.C0;
     st_base = first ? base0 : base1;
     st_soffa = (first ? c_kc : c_kc - p.C0) * 2;
-    st_soffb = st_live ? (chmajor ? ((c_kr * p.KW + c_kss) * Ctot + c_kc) * 2 : kt * (BK * 2)) : 0;
+    st_soffb = st_live ? (CHM ? ((c_kr * p.KW + c_kss) * Ctot + c_kc) * 2 : kt * (BK * 2)) : 0;
   };
   auto issue = [&](int idx, int buf) {  // idx is a compile-time constant after unrolling
     if (idx < A_IPW) {
@@ -529,28 +530,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
     // 8-row pass on exposed LDS / L2 latency, and the statistics another 0.45 k on a 48-shuffle butterfly plus sixteen
     // 8-lane stores). GroupNorm statistics of the block: per-lane partial sums over the block's passes, transposed through
     // the LDS rows just consumed, column sums by the lane that owns the column -> two dense 256-byte stores.
-    // (two flavours: 16-bit output with a 16-bit residual - the 16-bit engine - and fp32 output with an fp32 residual - the
-    // split mode of the fp32 path)
-    const bool f32o = p.out_f32 != 0;
-    const bool fast = !geglu && p.act == ACT_NONE && (p.N & 7) == 0 &&
-                      (!p.rowvec || p.rows_per_vec >= p.M || (p.rows_per_vec & 31) == 0) &&
-                      (f32o ? ((p.out_ld & 3) == 0 && (!p.resid || (p.resid_f32 && (p.resid_ld & 3) == 0)))
-                            : (!p.resid_f32 && (p.out_ld & 7) == 0 && (!p.resid || (p.resid_ld & 7) == 0)));
+    const bool fast = !geglu && !p.out_f32 && !p.resid_f32 && p.act == ACT_NONE && (p.N & 7) == 0 && (p.out_ld & 7) == 0 &&
+                      (!p.resid || (p.resid_ld & 7) == 0) && (!p.rowvec || p.rows_per_vec >= p.M || (p.rows_per_vec & 31) == 0);
     if (fast) {
       constexpr int LD = T::EPI_LD;
       const int RPP = 64 / (cw / 8), NP = 32 / RPP;  // rows per pass, passes per 32-row block (compile-time: cw is)
       const bool colok = n < p.N;
       bf16_t* const ocol = (bf16_t*)outp + n;
-      float* const ocol32 = (float*)outp + n;
       const bf16_t* const rcol = p.resid ? p.resid + (int64_t)zb * p.o_bs + n : nullptr;
-      const float* const rcol32 = p.resid ? (const float*)p.resid + (int64_t)zb * p.o_bs + n : nullptr;
 #pragma unroll
       for (int rb = 0; rb < TM / 32; ++rb) {
         const int mb = m0 + wm * TM + rb * 32;  // first row of the block
         if (mb < p.M) {                         // (uniform) ragged M: whole blocks beyond the last row do nothing
           f32x4 lo[4], hi[4];
           uint4 rr[4];
-          f32x4 rlo[4], rhi[4];
           bool ok[4];
 #pragma unroll
           for (int ps = 0; ps < 4; ++ps)
@@ -565,15 +558,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
               const int m = mb + ps * RPP + vr;
               ok[ps] = colok && m < p.M;
               rr[ps] = (uint4){0u, 0u, 0u, 0u};
-              rlo[ps] = (f32x4){0.f, 0.f, 0.f, 0.f}; rhi[ps] = rlo[ps];
-              if (rcol && ok[ps]) {
-                if (f32o) {
-                  rlo[ps] = *(const f32x4*)(rcol32 + (int64_t)m * p.resid_ld);
-                  rhi[ps] = *(const f32x4*)(rcol32 + (int64_t)m * p.resid_ld + 4);
-                } else {
-                  rr[ps] = *(const uint4*)(rcol + (int64_t)m * p.resid_ld);
-                }
-              }
+              if (rcol && ok[ps]) rr[ps] = *(const uint4*)(rcol + (int64_t)m * p.resid_ld);
             }
           float add[8];
 #pragma unroll
@@ -592,23 +577,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
               unpack8(rr[ps], rf);
 #pragma unroll
               for (int e = 0; e < 4; ++e) { v[e] = lo[ps][e] + add[e]; v[4 + e] = hi[ps][e] + add[4 + e]; }
-              if (f32o) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += rlo[ps][e]; v[4 + e] += rhi[ps][e]; }
-              } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += rf[e];
-              }
+              for (int e = 0; e < 8; ++e) v[e] += rf[e];
               if (ok[ps]) {
-                CD_PROBE_ONLY(if (!(p.dbg & 1))) {
-                  if (f32o) {
-                    float* op = ocol32 + (int64_t)(mb + ps * RPP + vr) * p.out_ld;
-                    *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
-                    *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                  } else {
-                    *(uint4*)(ocol + (int64_t)(mb + ps * RPP + vr) * p.out_ld) = pack8(v);
-                  }
-                }
+                CD_PROBE_ONLY(if (!(p.dbg & 1)))
+                *(uint4*)(ocol + (int64_t)(mb + ps * RPP + vr) * p.out_ld) = pack8(v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
               }
@@ -819,11 +792,23 @@ int launch_cfg(hipStream_t st, const ConvGemmParams& p) {
 #else
   constexpr int kLds = T::LDS_BYTES;
 #endif
+  // channel-major K order (ConvGemmParams::korder): 3 x 3 .. 8 x 8 filters without upsampling; everything else - 1 x 1, the
+  // CLIP patch embeddings, the nearest-x2 convs - runs the tap-major instantiation
+  // ... and only where it pays: the tap re-reads of a LARGE activation (>= 64 x 64 per sample, >= 32 MiB in all: the 64 x 64
+  // level of the U-Nets from 8 samples up, the first stages) miss the 4 MiB L2 in tap-major order - there the order cuts the
+  // fabric traffic by 45 % for 2 % of the conv's time (per-step offset update); on the 32 x 32 .. 8 x 8 levels the
+  // activations stay L2 / Infinity-Cache resident either way and the update costs 2-7 % (profiles/r4_k_order_in_situ.txt)
+  const int64_t a_bytes = (int64_t)p.B * p.Hs * p.Ws * (p.C0 + p.C1) * 2;
+  const bool chm = p.korder != 0 && p.KH * p.KW > 1 && p.KH <= 8 && p.KW <= 8 && !p.up &&
+                   (p.korder == 2 || (p.Hs * p.Ws >= 4096 && a_bytes >= (32ll << 20)));
   static std::once_flag attr_once;  // engines on several host threads launch the same instantiation
-  auto kern = k_conv_gemm<BM, BN, BK, WM, WN, NSTAGE>;
+  auto kern0 = k_conv_gemm<BM, BN, BK, WM, WN, NSTAGE, false>;
+  auto kern1 = k_conv_gemm<BM, BN, BK, WM, WN, NSTAGE, true>;
   std::call_once(attr_once, [&]() {
-    HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+    HIP_CHECK(hipFuncSetAttribute((const void*)kern0, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+    HIP_CHECK(hipFuncSetAttribute((const void*)kern1, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
   });
+  auto kern = chm ? kern1 : kern0;
   if (split > 1) {
     const SplitKWorkspace& ws = g_conv_splitk;
     CD_CHECK(p.sk_scratch && p.sk_flags, "conv_gemm: split-K without workspace");

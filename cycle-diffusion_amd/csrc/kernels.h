@@ -95,10 +95,11 @@ struct ConvGemmParams {
   // phase-timing build only (-DCD_PROBE, lib/libcyclediff_probe.so; scripts/probe_report.py): every wave leaves
   // kProbeWords 64-bit words of s_memtime stamps here, [block][wave][kProbeWords]; null = off
   unsigned long long* probe = nullptr;
-  // order of the K steps of a KH x KW > 1 convolution: 1 (default) = channel-major - the KH * KW taps of one BK-channel
-  // slice, then the next slice: the re-reads of an activation line by neighbouring taps follow each other within KH * KW
-  // steps and hit the XCD's L2 (round 4: hit rate 54 -> 72 %, fabric fetch of the 320-channel 3 x 3 conv 750 -> 409 MB);
-  // 0 = tap-major (all channels of a tap, then the next tap; CYCLEDIFF_KORDER=0 for A/B runs)
+  // order of the K steps of a KH x KW > 1 convolution: tap-major (all channels of a filter tap, then the next tap) or
+  // channel-major (the KH * KW taps of one BK-channel slice, then the next slice: the re-reads of an activation line by
+  // neighbouring taps follow each other within KH * KW steps and hit the XCD's L2 - round 4: hit rate 54 -> 72 %, fabric fetch
+  // of the 320-channel 3 x 3 conv at 64 x 64 750 -> 409 MB per launch). 1 (default) = channel-major where the activation is
+  // large (launch_cfg), 2 = wherever the kernel supports it, 0 = never (CYCLEDIFF_KORDER for A/B runs)
   int korder = 1;
   int dbg = 0;  // probe build: 1 = the epilogue skips its global stores, 2 = skips the statistics, 4 = every tile gathers
                 // its A rows from the first 1024 + BM rows (an L2-resident operand: what would the K loop do without misses?)
