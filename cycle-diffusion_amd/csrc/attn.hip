@@ -46,7 +46,10 @@ constexpr int KT = 64;  // keys per tile
 // written to the other LDS buffer after it - one barrier per tile.
 // NWV = waves per workgroup (32 queries each): 4, or 8 - a 256-query workgroup stages every K / V tile once for twice
 // the queries (half the L2 -> LDS traffic and half the staging instructions per query; same waves per SIMD)
-template <int DQK, int DV, int DH, int NBUF, bool VTOK, int KG, int NWV = 4>
+// DBG (probe build only, CD_ATTN_DBG: timing experiments whose RESULTS ARE WRONG - which part of a tile costs what):
+//   1 no K / V fetch and commit after the first tile   2 no barrier in the loop   8 no exponentials (p = s)
+//   16 no PV MFMAs   32 no QK^T MFMAs   64 no maximum / deferred-maximum test
+template <int DQK, int DV, int DH, int NBUF, bool VTOK, int KG, int NWV = 4, int DBG = 0>
 __global__ __launch_bounds__(64 * NWV, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3) : 2) : 1) void k_attention(AttnParams p) {
   constexpr int NT = 64 * NWV;  // threads per workgroup
   constexpr int KLD = DQK + 8;  // elements per K row in LDS (16 B pad)
@@ -195,9 +198,9 @@ __global__ __launch_bounds__(64 * NWV, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3)
     const int key0 = t * KT;
     const int buf = NBUF == 2 ? (t & 1) : 0;
     const bool more = t + 1 < ntiles;
-    if (more) fetch(key0 + KT);
-    const bf16_t* Kt = Ks[buf];
-    const bf16_t* Vt = Vs[buf];
+    if (more && !(DBG & 1)) fetch(key0 + KT);
+    const bf16_t* Kt = Ks[(DBG & 1) ? 0 : buf];
+    const bf16_t* Vt = Vs[(DBG & 1) ? 0 : buf];
 
     // The tile is consumed in groups of KG keys (KG = 64: both 32-key halves at once; KG = 32: one half at a time -
     // half the score / probability registers live, one more wave per SIMD where that crosses an occupancy step).
@@ -217,8 +220,16 @@ __global__ __launch_bounds__(64 * NWV, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3)
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-          for (int kh = 0; kh < HPG; ++kh)  // the 32-key halves alternate: no back-to-back dependent MFMAs
-            s[kh] = CD_MFMA_32x32x16(kf[kh][ks], qf[ks], ks == 0 ? negm : s[kh]);
+          for (int kh = 0; kh < HPG; ++kh) {  // the 32-key halves alternate: no back-to-back dependent MFMAs
+            if constexpr (DBG & 32) {
+              if (ks == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kh][r] = negm[r] + __builtin_bit_cast(float, (uint32_t)kf[kh][NKS - 1][r & 7] << 16) * 1e-30f;
+              }
+            } else {
+              s[kh] = CD_MFMA_32x32x16(kf[kh][ks], qf[ks], ks == 0 ? negm : s[kh]);
+            }
+          }
       }
       // ---- keys beyond Tk (last tile only) / causal mask
       if (key0 + KT > p.Tk || p.causal) {
@@ -238,6 +249,7 @@ __global__ __launch_bounds__(64 * NWV, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3)
       // (Rounds 1-2a started with the asm op: a latent hazard, visible as run-to-run differences once the 32-key groups
       // put the reader right behind a dependent MFMA chain.)
       float mx = __builtin_amdgcn_fmed3f(s[HPG - 1][14], s[HPG - 1][15], INFINITY);
+      if constexpr (!(DBG & 64)) {
       if (HPG == 2) {
 #pragma unroll
         for (int r = 0; r < 14; r += 2)
@@ -246,11 +258,12 @@ __global__ __launch_bounds__(64 * NWV, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3)
 #pragma unroll
       for (int r = 0; r < (HPG == 2 ? 16 : 14); r += 2)
         asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[0][r]), "v"(s[0][r + 1]));
+      }
       // ---- move m (rare, wave-uniform): always on the first group, later only if a row grew past 2^kDefer.
       // Textbook order: the decision precedes the exponentiation of the keys it covers, and everything
       // accumulated against the old m (o, the row sums inside o or l_part) is rescaled exactly once.
       const bool first = t == 0 && g == 0;
-      if (first || __any(mx > kDefer)) {
+      if (first || (!(DBG & 64) && __any(mx > kDefer))) {
         const float mxq = fmaxf(mx, __shfl_xor(mx, 32));  // both half-lanes of a query agree
         float delta = first ? mxq : fmaxf(mxq, 0.f);
         delta = delta == -INFINITY ? 0.f : delta;
@@ -275,8 +288,8 @@ __global__ __launch_bounds__(64 * NWV, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3)
       for (int kh = 0; kh < HPG; ++kh)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const float e0 = __builtin_amdgcn_exp2f(s[kh][r]);
-          const float e1 = __builtin_amdgcn_exp2f(s[kh][r + 1]);
+          const float e0 = (DBG & 8) ? s[kh][r] : __builtin_amdgcn_exp2f(s[kh][r]);
+          const float e1 = (DBG & 8) ? s[kh][r + 1] : __builtin_amdgcn_exp2f(s[kh][r + 1]);
           if (!ONES) ps += e0 + e1;
           pw[kh][r >> 1] = pack2_prob(e0, e1);
         }
@@ -302,14 +315,15 @@ __global__ __launch_bounds__(64 * NWV, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3)
             } else {
               vf = *(const bf16x8*)(Vt + (dt * 32 + qi) * VLD + k16 + 8 * half);
             }
-            o[dt] = CD_MFMA_32x32x16(vf, pf, o[dt]);
+            if constexpr (DBG & 16) o[dt][0] += __builtin_bit_cast(float, (uint32_t)vf[0] << 16) * __builtin_bit_cast(float, praw.x);
+            else o[dt] = CD_MFMA_32x32x16(vf, pf, o[dt]);
           }
         }
     }
 
-    if (NBUF == 1) __syncthreads();
-    if (more) commit(NBUF == 2 ? (buf ^ 1) : 0);
-    __syncthreads();
+    if (NBUF == 1 && !(DBG & 2)) __syncthreads();
+    if (more && !(DBG & 1)) commit(NBUF == 2 ? (buf ^ 1) : 0);
+    if (!(DBG & 2)) __syncthreads();
   }
 
   // ---- normalise and store: lane owns query q0+qi and 4 consecutive d per register quad
@@ -394,6 +408,30 @@ void launch_attention(hipStream_t st, const AttnParams& p) {
   // 256-query workgroups (8 waves) for the long self-attention of the 64 x 64 level: CD_ATTN_W8=0 selects 128 (A/B)
   static const bool wide_wg = [] { const char* e = getenv("CD_ATTN_W8"); return !(e && e[0] == '0'); }();
   if (p.D == 40 && half_groups && wide_wg && p.Tq >= 1024 && p.Tk >= 1024 && p.vt) {
+#ifdef CD_PROBE
+    static const int dbg = [] { const char* e = getenv("CD_ATTN_DBG"); return e ? atoi(e) : 0; }();
+    const dim3 g8(ceil_div(p.Tq, 256), p.H, p.B);
+    // CD_ATTN_TIME=1: kernel time of every launch by events on its stream (printed; the probe build is never the product)
+    static const bool timed = getenv("CD_ATTN_TIME") != nullptr;
+    struct Timer {
+      hipStream_t st; bool on; hipEvent_t e0, e1;
+      Timer(hipStream_t s, bool o) : st(s), on(o) { if (on) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, st); } }
+      ~Timer() {
+        if (!on) return;
+        hipEventRecord(e1, st); hipEventSynchronize(e1);
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        printf("[attn d40 w8 dbg %d] %.1f us\n", dbg, ms * 1e3f);
+        hipEventDestroy(e0); hipEventDestroy(e1);
+      }
+    } timer(st, timed);
+#define CD_ATTN_DBG_CASE(V) case V: hipLaunchKernelGGL((k_attention<48, 64, 40, 2, false, 32, 8, V>), g8, dim3(512), 0, st, p); return;
+    switch (dbg) {
+      CD_ATTN_DBG_CASE(1) CD_ATTN_DBG_CASE(2) CD_ATTN_DBG_CASE(3) CD_ATTN_DBG_CASE(8) CD_ATTN_DBG_CASE(16) CD_ATTN_DBG_CASE(32)
+      CD_ATTN_DBG_CASE(48) CD_ATTN_DBG_CASE(64) CD_ATTN_DBG_CASE(72) CD_ATTN_DBG_CASE(75) CD_ATTN_DBG_CASE(51)
+      default: break;
+    }
+#undef CD_ATTN_DBG_CASE
+#endif
     hipLaunchKernelGGL((k_attention<48, 64, 40, 2, false, 32, 8>), dim3(ceil_div(p.Tq, 256), p.H, p.B), dim3(512), 0, st,
                        p);
   } else if (p.D == 40 && half_groups) CD_ATTN_KG(48, 64, 40, 2, 32);
