@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string>
 #include <stdexcept>
+#include <atomic>
 
 namespace cd {
 
@@ -167,6 +168,22 @@ struct Error : public std::runtime_error {
                         ": HIP error " + hipGetErrorString(_e) + " in " #expr);      \
     }                                                                                \
   } while (0)
+
+// Once per DEVICE and process: kernel function attributes (hipFuncSetAttribute) belong to the device that is current when
+// they are set, and one process may drive engines on several GPUs (and on several host threads). The body is idempotent,
+// so two threads racing through it on the same device is harmless; the fast path is one relaxed device query and a load.
+struct PerDeviceOnce {
+  std::atomic<unsigned long long> done{0};
+  template <class F>
+  void operator()(F&& body) {
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    body();
+    done.fetch_or(bit, std::memory_order_release);
+  }
+};
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

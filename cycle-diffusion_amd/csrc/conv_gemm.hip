@@ -801,10 +801,10 @@ int launch_cfg(hipStream_t st, const ConvGemmParams& p) {
   const int64_t a_bytes = (int64_t)p.B * p.Hs * p.Ws * (p.C0 + p.C1) * 2;
   const bool chm = p.korder != 0 && p.KH * p.KW > 1 && p.KH <= 8 && p.KW <= 8 && !p.up &&
                    (p.korder == 2 || (p.Hs * p.Ws >= 4096 && a_bytes >= (32ll << 20)));
-  static std::once_flag attr_once;  // engines on several host threads launch the same instantiation
+  static PerDeviceOnce attr_once;  // engines on several host threads / devices launch the same instantiation
   auto kern0 = k_conv_gemm<BM, BN, BK, WM, WN, NSTAGE, false>;
   auto kern1 = k_conv_gemm<BM, BN, BK, WM, WN, NSTAGE, true>;
-  std::call_once(attr_once, [&]() {
+  attr_once([&]() {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern0, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
     HIP_CHECK(hipFuncSetAttribute((const void*)kern1, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
   });

@@ -353,8 +353,8 @@ void launch_vq_quantize(hipStream_t st, const float* z, float in_mul, const floa
   CD_CHECK(zc >= 1 && zc <= 8 && n_embed > 0, "vq_quantize: embed_dim %d / n_embed %d", zc, n_embed);
   const size_t lds = (size_t)n_embed * zc * sizeof(float);
   CD_CHECK(lds <= 150 * 1024, "vq_quantize: codebook of %zu bytes does not fit LDS", lds);
-  static std::once_flag attr_once;  // engines on several host threads may reach this launch together
-  std::call_once(attr_once, [&]() {
+  static PerDeviceOnce attr_once;  // engines on several host threads / devices may reach this launch together
+  attr_once([&]() {
     HIP_CHECK(hipFuncSetAttribute((const void*)k_vq_quantize, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   });
   const int64_t n = (int64_t)B * HW;

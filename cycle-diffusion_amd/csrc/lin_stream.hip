@@ -516,9 +516,9 @@ __global__ void k_fold_ln(const bf16_t* __restrict__ w, int ldw, const float* __
 
 template <int ACT, bool RESID, bool STATS, bool LNF = false>
 void launch_variant(hipStream_t st, const LinStreamParams& p, int grid) {
-  static std::once_flag attr_once;
+  static PerDeviceOnce attr_once;
   auto kern = k_lin_stream<ACT, RESID, STATS, LNF>;
-  std::call_once(attr_once, [&]() {
+  attr_once([&]() {
     HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   });
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, st, p);
@@ -550,12 +550,15 @@ void launch_lin_stream(hipStream_t st, const ConvGemmParams& c) {
   p.a = c.src0; p.lda = c.ld0; p.wfrag = c.wgt_frag; p.bias = c.bias;
   p.resid = c.resid; p.ldr = c.resid_ld; p.out = (bf16_t*)c.out; p.ldo = c.out_ld;
   p.stats = c.stats; p.M = c.M; p.N = c.N;
-  static int ncu = 0;
+  static std::atomic<int> ncu_of[64];  // CU count per device (one persistent workgroup per CU)
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  int ncu = ncu_of[dev & 63].load(std::memory_order_relaxed);
   if (!ncu) {
-    int dev = 0; hipDeviceProp_t prop;
-    HIP_CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, dev));
     ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ncu_of[dev & 63].store(ncu, std::memory_order_relaxed);
   }
   const int nstrips = (p.M + 255) / 256;
   const int grid = nstrips < ncu ? nstrips : ncu;

@@ -277,8 +277,11 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
             for j0 in range(0, len(img_ensemble), per_call):
                 chunk = img_ensemble[j0:j0 + per_call]
                 n = len(chunk)
-                sc = self.ranker(torch.cat(chunk, dim=0), original_img.repeat(n, 1, 1, 1), list(encode_text) * n,
-                                 list(decode_text) * n)
+                if hasattr(self.ranker, "score_folded"):  # the built-in ranker encodes texts and source images once
+                    sc = self.ranker.score_folded(torch.cat(chunk, dim=0), original_img, encode_text, decode_text, n)
+                else:
+                    sc = self.ranker(torch.cat(chunk, dim=0), original_img.repeat(n, 1, 1, 1), list(encode_text) * n,
+                                     list(decode_text) * n)
                 sc = sc[1] if isinstance(sc, (tuple, list)) else sc
                 parts.append(sc.view(n, bsz).t())
             scores = torch.cat(parts, dim=1)

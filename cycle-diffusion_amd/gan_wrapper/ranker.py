@@ -85,3 +85,19 @@ class DirectionalCLIPHIP:
             clip_score = torch.einsum("bz,bz->b", im, tgt)
             dclip_score = torch.einsum("bz,bz->b", n(im - orig), n(tgt - src))
         return clip_score, dclip_score
+
+    def score_folded(self, img, original_img, encode_text, decode_text, n):
+        """The same scores for `n` candidates of one batch concatenated along dim 0 (img: [n * B, ...], candidate-major), with
+        the text towers and the source images encoded ONCE and broadcast over the candidates - what a folded ensemble call
+        would otherwise recompute n times (the scores are per sample: clean_clip.py:24-31 has no cross-sample term)."""
+        bsz = original_img.shape[0]
+        assert img.shape[0] == n * bsz and len(encode_text) == bsz and len(decode_text) == bsz
+        nrm = lambda t: t / t.norm(dim=-1, keepdim=True)
+        with torch.no_grad():
+            src, tgt = nrm(self.features(text=list(encode_text))), nrm(self.features(text=list(decode_text)))
+            orig = nrm(self.features(img=original_img))
+            im = nrm(self.features(img=img))
+            src, tgt, orig = src.repeat(n, 1), tgt.repeat(n, 1), orig.repeat(n, 1)
+            clip_score = torch.einsum("bz,bz->b", im, tgt)
+            dclip_score = torch.einsum("bz,bz->b", nrm(im - orig), nrm(tgt - src))
+        return clip_score, dclip_score

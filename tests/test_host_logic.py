@@ -209,3 +209,44 @@ def test_unconditional_ldm_wrapper_refuses_the_lossy_16bit_engine_by_default():
         LatentDiffStochasticWrapper("celeba256", custom_steps=99, eta=0.1, white_box_steps=100, precision="fp16")
     with pytest.raises(ValueError, match="precision must be one of"):
         LatentDiffStochasticWrapper("celeba256", custom_steps=99, eta=0.1, white_box_steps=100, precision="tf32")
+
+
+def test_ranker_scores_a_folded_ensemble_with_texts_and_sources_encoded_once():
+    """DirectionalCLIPHIP.score_folded (ranker.py) = __call__ on the repeated inputs (what a user-supplied ranker gets from
+    a folded ensemble call, latent_text_wrapper.forward), with one text / source-image encoder pass instead of n
+    (reference scoring: model/energy/clean_clip.py:24-31, per sample). Towers replaced by a deterministic stand-in."""
+    import torch
+    from cycle_diffusion_amd.gan_wrapper import ranker as R
+
+    class FakeEngine:
+        device = torch.device("cpu")
+
+        def __init__(self):
+            self.calls = {"text": 0, "image": 0}
+            g = torch.Generator().manual_seed(3)
+            self.wt, self.wi = torch.randn(77, 16, generator=g), torch.randn(3 * 224 * 224, 16, generator=g) / 100
+
+        def clip_text_features(self, net, ids):
+            self.calls["text"] += ids.shape[0]
+            return (torch.sin(ids.double() * 0.37) @ self.wt.double()).float()
+
+        def clip_image_features(self, net, x):
+            self.calls["image"] += x.shape[0]
+            return (x.reshape(x.shape[0], -1).double() @ self.wi.double()).float()  # (fp64: batch-size independent sums)
+
+    rk = R.DirectionalCLIPHIP.__new__(R.DirectionalCLIPHIP)
+    rk.engine, rk.text, rk.vision = FakeEngine(), None, None
+    rk.tokenize = R._ClipTokenize()
+    g = torch.Generator().manual_seed(0)
+    bsz, n = 2, 3
+    orig = torch.rand(bsz, 3, 64, 64, generator=g)
+    cands = torch.rand(n * bsz, 3, 64, 64, generator=g)
+    enc, dec = ["a photo of a cat", "a dog"], ["a photo of a tiger", "a wolf"]
+    ref = rk(cands, orig.repeat(n, 1, 1, 1), enc * n, dec * n)
+    per_call = dict(rk.engine.calls)
+    rk.engine.calls = {"text": 0, "image": 0}
+    got = rk.score_folded(cands, orig, enc, dec, n)
+    for a, b in zip(ref, got):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    assert per_call == {"text": 2 * n * bsz, "image": 2 * n * bsz}
+    assert rk.engine.calls == {"text": 2 * bsz, "image": (n + 1) * bsz}
