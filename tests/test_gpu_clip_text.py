@@ -152,3 +152,9 @@ def test_openai_clip_vit_b32_and_directional_scores(engine, report):
                dclip_score_err=float((ds.cpu() - rds).abs().max()))
     assert e_img < 8e-3 * FMT and e_txt < 8e-3 * FMT, (e_img, e_txt)
     assert (cs.cpu() - rcs).abs().max() < 5e-3 * FMT and (ds.cpu() - rds).abs().max() < 2e-2 * FMT
+    # a folded ensemble call (latent_text_wrapper.forward): two candidates per sample, texts and sources encoded once
+    cand = torch.cat([img, torch.rand(2, 3, 512, 512, generator=g)], dim=0).cuda()
+    cs2, ds2 = rk.score_folded(cand, orig.cuda(), src, tgt, 2)
+    cs1, ds1 = rk(cand, orig.cuda().repeat(2, 1, 1, 1), src * 2, tgt * 2)
+    assert (cs2 - cs1).abs().max() < 1e-3 * FMT and (ds2 - ds1).abs().max() < 4e-3 * FMT
+    assert (cs2[:2].cpu() - rcs).abs().max() < 5e-3 * FMT
