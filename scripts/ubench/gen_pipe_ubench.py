@@ -288,6 +288,13 @@ def attn_kernel(name, barrier=True, order="product", staging=True, wps=4, data="
             a("v_mov_b32 v%d, 0x38003800" % r) if r < 20 else a("v_mov_b32 v%d, 0xc2480000" % r)   # q = 0.5, -m = -50
     for r in range(88, 120):
         a("v_mov_b32 v%d, 0" % r)
+    if order == "q64":
+        for r in range(12):
+            a("v_mov_b32 v%d, v%d" % (140 + r, 8 + (r + 4) % 12))   # block B's queries: another arrangement of the same random values
+        for r in range(16):
+            a("v_mov_b32 v%d, v%d" % (152 + r, 20 + r))
+        for r in range(192, 224):
+            a("v_mov_b32 v%d, 0" % r)
     a("s_mov_b32 s20, %[iters]")
     a("s_mov_b32 s21, 0")
     a("L_loop_%=:")
@@ -404,6 +411,45 @@ def attn_kernel(name, barrier=True, order="product", staging=True, wps=4, data="
                 else:
                     a("s_waitcnt lgkmcnt(0)")
                     mf(1, 3, 1)
+        elif order == "q64":
+            # 64 queries per wave (two 32-query blocks A / B share every K and V^T fragment read): half the LDS reads and half the
+            # staging per score, two independent MFMA chains to interleave; ~210 VGPRs = 2 waves per SIMD
+            def kread(g, ks):
+                a("ds_read_b128 v[%d:%d], %%[kad] offset:%d" % (52 + 4 * ks, 55 + 4 * ks, KB[buf] + g * 32 * 112 + ks * 32))
+            QF = {"A": 8, "B": 140}; NM = {"A": 20, "B": 152}; SR = {"A": 36, "B": 168}; PW = {"A": 64, "B": 184}; OO = {"A": 88, "B": 192}
+            def soft(blk):
+                sreg, pw = SR[blk], PW[blk]
+                a("v_max_f32 v6, v%d, v%d" % (sreg + 15, sreg + 15))
+                a("v_max_f32 v7, v%d, v%d" % (sreg + 14, sreg + 14))
+                a("v_max_f32 v6, v7, v6")
+                for r in range(0, 14, 2):
+                    a("v_max3_f32 v6, v6, v%d, v%d" % (sreg + r, sreg + r + 1))
+                a("v_cmp_lt_f32 vcc, %[defer], v6")
+                for r in range(16):
+                    a("v_exp_f32 v%d, v%d" % (sreg + r, sreg + r))
+                for r in range(8):
+                    a("v_cvt_pk_f16_f32 v%d, v%d, v%d" % (pw + r, sreg + 2 * r, sreg + 2 * r + 1))
+                for r in range(6):
+                    a("v_add_u32 v7, v7, v6")
+            for g in range(2):
+                for ks in range(3):
+                    kread(g, ks)
+                a("s_waitcnt lgkmcnt(0)")
+                for ks in range(3):
+                    for blk in ("A", "B"):
+                        c = "v[%d:%d]" % (NM[blk], NM[blk] + 15) if ks == 0 else "v[%d:%d]" % (SR[blk], SR[blk] + 15)
+                        a("v_mfma_f32_32x32x16_f16 v[%d:%d], v[%d:%d], v[%d:%d], %s" % (SR[blk], SR[blk] + 15, 52 + 4 * ks, 55 + 4 * ks, QF[blk] + 4 * ks, QF[blk] + 4 * ks + 3, c))
+                vreads(g, buf)
+                a("s_nop 6")
+                soft("A")
+                soft("B")
+                a("s_waitcnt lgkmcnt(0)")
+                for s2 in range(2):
+                    for dt in range(2):
+                        i = s2 * 2 + dt
+                        for blk in ("A", "B"):
+                            o = OO[blk] + 16 * dt
+                            a("v_mfma_f32_32x32x16_f16 v[%d:%d], v[%d:%d], v[%d:%d], v[%d:%d]" % (o, o + 15, 72 + 4 * i, 75 + 4 * i, PW[blk] + 4 * s2, PW[blk] + 4 * s2 + 3, o, o + 15))
         elif order == "qk_ahead":
             qk(0, buf, S0)
             qk(1, buf, S1)
@@ -438,7 +484,7 @@ def attn_kernel(name, barrier=True, order="product", staging=True, wps=4, data="
     a("s_nop 15")
     a("s_nop 15")
     a("v_add_f32 %[res], v88, v7")
-    top = 144 if order == "qk_ahead" else 128
+    top = 144 if order == "qk_ahead" else (224 if order == "q64" else 128)
     clob = ["v%d" % r for r in range(6, top)] + ["s20", "s21", "s22", "scc", "vcc", "memory"]
     body = "\n".join('      "%s\\n"' % l for l in lines)
     emit("""
@@ -466,7 +512,7 @@ __global__ __launch_bounds__(512, %d) void %s(int iters, const char* src, float*
   if (res == 123.456f) sink[0] = res;
 }
 """ % (wps, name, body, ", ".join('"%s"' % c for c in clob)))
-    return dict(name=name, wps=wps)
+    return dict(name=name, wps=wps, qblocks=2 if order == "q64" else 1)
 
 
 def mix_kernel(name, mode):
@@ -624,7 +670,9 @@ attns = [attn_kernel("k_att_product"), attn_kernel("k_att_nobarrier", barrier=Fa
          attn_kernel("k_att_rand_noqk", order="compiled", data="random", skip=("qk",)),
          attn_kernel("k_att_rand_nomfma", order="compiled", data="random", skip=("qk", "pv")),
          attn_kernel("k_att_rand_nostage", order="compiled", data="random", staging=False, barrier=False),
-         attn_kernel("k_att_rand_w2", order="compiled", data="random", wps=2)]
+         attn_kernel("k_att_rand_w2", order="compiled", data="random", wps=2),
+         attn_kernel("k_att_rand_q64", order="q64", data="random", wps=2),
+         attn_kernel("k_att_zero_q64", order="q64", wps=2)]
 mixes = [mix_kernel("k_mix_" + m, m) for m in ("mfma", "valu", "exp", "fma", "both", "both_exp", "both_fma", "split")]
 
 emit("""
@@ -682,7 +730,7 @@ for m in mixes:
   }
 """ % m)
 emit("""  printf("\\nattention skeleton (k_attention<48,64,40,2,false,32,8>): SIMD cycles per wave and 64-key tile (product, rocprof counters: ~1000)\\n");
-  printf("%-22s %4s %12s %8s %8s\\n", "kernel", "w/S", "cycles", "GHz", "ns");
+  printf("%-22s %4s %12s %8s %8s   (ns per 32-query block of a wave and 64-key tile)\\n", "kernel", "w/S", "cycles", "GHz", "ns");
 """)
 for t in attns:
     emit("""  if (strstr("%(name)s", only)) {
@@ -692,7 +740,7 @@ for t in attns:
     const Res r = run(%(name)s, 512, lds, 4000, src, sink, clk, 256 * wgs_per_cu);
     // a workgroup's 8 waves put 2 on every SIMD; with wgs_per_cu resident workgroups a SIMD runs 2 * wgs_per_cu wave-tiles per tile step
     printf("%%-22s %%4d %%12.1f %%8.3f %%8.1f\\n", "%(name)s", 2 * wgs_per_cu, r.cyc_per_iter / 2.0 / (2 * wgs_per_cu), r.ghz,
-           r.cyc_per_iter / 2.0 / (2 * wgs_per_cu) / r.ghz);
+           r.cyc_per_iter / 2.0 / (2 * wgs_per_cu) / r.ghz / %(qblocks)d);
   }
 """ % t)
 emit("""  return 0;
