@@ -565,6 +565,16 @@ def main():
         peak = PEAK_F32_TFLOPS if f32 else (PEAK_TFLOPS / 3.0 if x3 else PEAK_TFLOPS)
         ach = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         traffic = pmc_traffic_per_launch() if a.workload == "c2" else None
+        # the ceiling of THIS device on this lease, after the timed region: a bare 16-bit MFMA loop on every CU settles
+        # where the package power cap lets it (MI355X, 1400 W: 1.7-1.8 GHz = 1.7-1.8 PFLOP/s)
+        sustained = None
+        if not f32:
+            try:
+                s_tf, s_ghz = eng.mfma_sustained(300)
+                sustained = {"tflops": s_tf, "ghz": s_ghz, "what": "bare v_mfma_f32_32x32x16 loop on random operands, every "
+                             "CU, 0.3 s, after the timed region (csrc/diag.hip)"}
+            except Exception as e:  # noqa: BLE001 - a diagnostic never fails the bench line
+                sustained = {"error": "%s: %s" % (type(e).__name__, e)}
         fmt = "fp16" if eng.lib.cd_act_format() == 1 else "bf16"
         res = {
             "metric": wl["metric"], "value": ips, "unit": "images/s",
@@ -602,6 +612,10 @@ def main():
                          "algorithmic_tflop_per_step": k_flops / 1e12 / C,
                          "whole_path_frac": ips * wl["flop_per_image"] / 1e12 / (world * peak)},
         }
+        if sustained is not None:
+            res["roofline"]["sustained_peak"] = sustained
+            if sustained.get("tflops"):
+                res["roofline"]["frac_of_sustained"] = ach / (sustained["tflops"] / (3.0 if x3 else 1.0))
         if ensemble:
             n_cand = (wrapper.n_trials * len(wrapper.skip_steps) * len(wrapper.encoder_unconditional_guidance_scales) *
                       len(wrapper.decoder_unconditional_guidance_scales))

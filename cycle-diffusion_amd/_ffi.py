@@ -82,6 +82,7 @@ SIGNATURES = {
     "cd_op_timestep_embedding": [_VP, _VP, _I, _I, _I, _VP],
     "cd_op_sched_step": [_VP, _I, _I, _VP, _VP, _VP, _VP, _I, _F, _VP, _VP, _I, _I, _I, _I, _VP],
     "cd_op_bench_conv": [_VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float)],
+    "cd_op_bench_mfma_sustained": [_VP, _I, C.POINTER(C.c_float), C.POINTER(C.c_float)],
     "cd_op_probe": [_VP, _I, _VP, _VP, _SZ],
 }
 _RESTYPES = {"cd_last_error": C.c_char_p}

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libcyclediff.so")
-SOURCES = ["sched.hip", "elementwise.hip", "norm.hip", "conv_gemm.hip", "lin_stream.hip", "attn.hip", "f32_path.hip", "st_f32.hip", "engine.hip",
+SOURCES = ["sched.hip", "elementwise.hip", "norm.hip", "conv_gemm.hip", "lin_stream.hip", "attn.hip", "f32_path.hip", "st_f32.hip", "diag.hip", "engine.hip",
            "unet_openai.hip", "nets_ho_vae.hip", "clip_text.hip", "capi.hip"]
 HEADERS = ["common.h", "kernels.h", "engine.h", os.path.join("..", "..", "include", "cyclediff.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -987,6 +987,14 @@ extern "C" int cd_op_bench_conv(cd_handle h, int B, int H, int W, int C0, int C1
   CD_API_END
 }
 
+extern "C" int cd_op_bench_mfma_sustained(cd_handle h, int target_ms, float* tflops_out, float* ghz_out) {
+  CD_API_BEGIN
+  enter_engine(h);
+  CD_CHECK(h && tflops_out && ghz_out && target_ms > 0 && target_ms <= 5000, "bad argument");
+  launch_mfma_sustained(h->st, target_ms, tflops_out, ghz_out);
+  CD_API_END
+}
+
 extern "C" int cd_op_probe(cd_handle h, int which, const void* in, void* out, size_t n) {
   CD_API_BEGIN
   enter_engine(h);

@@ -229,6 +229,10 @@ void launch_attention(hipStream_t st, const AttnParams& p);
 void launch_transpose_v(hipStream_t st, const bf16_t* v, int ldv, int64_t v_bs, bf16_t* vt, int B,
                         int H, int Tk, int D, int Dpad, int Tpad);
 
+// ---------------------------------------------------------------- diagnostics (diag.hip)
+// sustained 16-bit MFMA rate of this device under its power cap: bare MFMA loop on every CU for ~target_ms
+void launch_mfma_sustained(hipStream_t st, int target_ms, float* tflops, float* ghz);
+
 // ---------------------------------------------------------------- elementwise (elementwise.hip)
 // fp32 NCHW [B][C][HW] -> bf16 NHWC [B][HW][Cpad] (pad channels zero), y = x*scale + shift
 void launch_nchw_to_nhwc(hipStream_t st, const float* x, bf16_t* y, int B, int C, int HW, int Cpad,

@@ -357,6 +357,13 @@ class Engine:
         check(self.lib.cd_prof_collect(self.h, C.byref(n), C.byref(ms), C.byref(fl)))
         return n.value, ms.value, fl.value
 
+    def mfma_sustained(self, target_ms=300):
+        """(TFLOP/s, GHz) of a bare 16-bit MFMA loop on every CU for ~target_ms: what this device's matrix cores sustain
+        under its power cap (csrc/diag.hip). Measurement support for bench.py, not part of the path."""
+        tf, ghz = C.c_float(), C.c_float()
+        check(self.lib.cd_op_bench_mfma_sustained(self.h, int(target_ms), C.byref(tf), C.byref(ghz)))
+        return tf.value, ghz.value
+
     def workspace_high_water(self):
         v = C.c_size_t()
         check(self.lib.cd_engine_workspace_high_water(self.h, C.byref(v)))

@@ -217,6 +217,9 @@ int cd_op_sched_step(cd_handle h, int mode, int sched_kind, const cd_step_coef* 
  * act: low byte = activation; | 0x100 = in-place residual update of the output; | 0x200 = fused GroupNorm statistics */
 int cd_op_bench_conv(cd_handle h, int B, int H, int W, int C0, int C1, int N, int k, int stride, int up,
                      int act, int tile, int iters, float* ms_out);
+/* what the matrix cores of this device sustain on 16-bit operands under its power cap: a bare MFMA loop on every CU for
+ * about target_ms (no reference counterpart: measurement support for bench.py's roofline object) */
+int cd_op_bench_mfma_sustained(cd_handle h, int target_ms, float* tflops_out, float* ghz_out);
 /* raw MFMA / LDS layout probe used by tests/test_gpu_ops.py */
 int cd_op_probe(cd_handle h, int which, const void* in, void* out, size_t n);
 

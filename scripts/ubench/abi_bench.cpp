@@ -2,6 +2,7 @@
 // (the first `import torch` there costs one to two minutes of a metered call; this starts in a second):
 //
 //   abi_bench conv  B H C0 C1 N k stride up act tile iters      -> cd_op_bench_conv (ms per launch, TFLOP/s)
+//   abi_bench peak  [ms]                                        -> cd_op_bench_mfma_sustained (TFLOP/s, GHz)
 //   abi_bench attn  B T H D v_transposed iters [Tk]             -> cd_op_attention  (ms per call incl. the fp32 <-> 16-bit
 //                                                                   layout conversions of that entry point; kernel time:
 //                                                                   rocprofv3 --kernel-trace -- abi_bench attn ...)
@@ -61,6 +62,12 @@ int main(int argc, char** argv) {
     const double fl = 2.0 * B * ho * ho * (double)N * k * k * (C0 + C1);
     printf("conv B%d %dx%d C%d+%d -> N%d k%d s%d up%d act%d tile %d: %.3f ms  %.1f TFLOP/s\n", B, H, H, C0, C1, N, k, stride,
            up, act, tile, ms, fl / ms * 1e-9);
+  } else if (!strcmp(argv[1], "peak")) {  // abi_bench peak [ms]: sustained 16-bit MFMA rate of this device (cd_op_bench_mfma_sustained)
+    float tf = 0, ghz = 0;
+    for (int r = 0; r < 3; ++r) {
+      CD_OK(cd_op_bench_mfma_sustained(h, argc > 2 ? atoi(argv[2]) : 300, &tf, &ghz));
+      printf("sustained MFMA rate: %.1f TFLOP/s at %.3f GHz\n", tf, ghz);
+    }
   } else if (!strcmp(argv[1], "attn")) {
     if (argc < 8) { fprintf(stderr, "attn needs 6 arguments\n"); return 2; }
     const int B = atoi(argv[2]), T = atoi(argv[3]), H = atoi(argv[4]), D = atoi(argv[5]), vt = atoi(argv[6]),

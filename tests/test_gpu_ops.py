@@ -457,3 +457,12 @@ def test_sched_steps_bit_exact(engine, report):
     got_xn, _ = _ops.sched_step(engine, 1, 0, co, x0=x0, xt=xt, eps_hat=e_c, noise=None, is_last=True)
     assert torch.equal(got_xn, x0)
     report.add("sched_steps_bit_exact", ok=True)
+
+
+def test_sustained_mfma_rate_diagnostic_is_consistent(engine):
+    """cd_op_bench_mfma_sustained (csrc/diag.hip): the rate it reports is the clock it reports x 1024 SIMDs x 1024 flop per
+    cycle at 90-100 % duty, inside what an MI355X can do (bench.py puts it beside roofline.peak)."""
+    tf, ghz = engine.mfma_sustained(150)
+    assert 0.8 < ghz < 2.6 and 600 < tf < 2600, (tf, ghz)
+    duty = tf / (ghz * 1024 * 1024 * 1e-3)
+    assert 0.85 < duty < 1.03, (tf, ghz, duty)
