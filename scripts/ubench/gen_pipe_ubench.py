@@ -133,7 +133,7 @@ __global__ __launch_bounds__(%d) void %s(int iters, const char* src, float* sink
                 fill=2 * fill_per_wave * waves if fill else 0, lds=100 * 1024)
 
 
-def kloop_kernel(name, waves, mt, nt, rd, sync, swz):
+def kloop_kernel(name, waves, mt, nt, rd, sync, swz, shared_b=False):
     """Ablation ladder from the ideal loop towards conv_gemm.hip's K loop (BK = 64, 2-deep ring). One loop iteration = one K
     step of 64 = 4 k16 segments; fragment sets alternate.
       rd   'spread': the next segment's fragment reads sit between this segment's MFMAs, one lgkmcnt(0) per segment
@@ -142,6 +142,9 @@ def kloop_kernel(name, waves, mt, nt, rd, sync, swz):
       sync 'none'  : refill instructions spread over the K step, counted wait only
            'wait'  : at the product's sync point (middle of segment 3): s_waitcnt vmcnt(0), then the whole refill back to back
            'barrier': the same + s_barrier (the product)
+      shared_b  the B part of the refill (5 of 9 pieces per wave: the weight tile) reads the SAME addresses in every workgroup, as
+           the product does when one weight tile serves all row tiles (N = 320: every CU streams the whole weight matrix) -
+           the A part stays private; otherwise every workgroup streams its own window
       swz  fragment reads use the product's LDS layout (128-byte rows, XOR-swizzled 16-byte chunks) instead of lane-linear 1-KiB blocks"""
     per_set, nacc = mt + nt, mt * nt
     agpr = waves == 4
@@ -194,7 +197,8 @@ def kloop_kernel(name, waves, mt, nt, rd, sync, swz):
                     if sync == "barrier":
                         a("s_barrier")
                     for f in range(lpt):
-                        a("buffer_load_dwordx4 %%[voff], %%[rsrc], 0 offen offset:%d lds" % (f * 1024 % 4096))
+                        vo = "%[voffb]" if (shared_b and f >= lpt * 4 // 9) else "%[voff]"
+                        a("buffer_load_dwordx4 %s, %%[rsrc], 0 offen offset:%d lds" % (vo, f * 1024 % 4096))
             if sync == "none":
                 tot = (seg * nacc + n + 1) * lpt // (4 * nacc)
                 while fills_done < tot:
@@ -244,6 +248,7 @@ __global__ __launch_bounds__(%d) void %s(int iters, const char* src, float* sink
   const unsigned sw0 = (unsigned)(row * 128 + ((half ^ ((row >> 1) & 7)) * 16));
   const unsigned ad0 = %s, ad1 = ad0 ^ 32u, ad2 = ad0 ^ 64u, ad3 = ad0 ^ 96u;
   const unsigned voff = (unsigned)(((blockIdx.x * %d + wave) * 4096 + lane * 16) & 0x1fffff);
+  const unsigned voffb = (unsigned)(0x200000 + wave * 4096 + lane * 16);  // the same 32 KiB for every workgroup
   const u32x4 rsrc = make_rsrc(src);
   const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane(40960 + wave * 4096);
   float res;
@@ -251,7 +256,8 @@ __global__ __launch_bounds__(%d) void %s(int iters, const char* src, float* sink
   asm volatile(
 %s
       : [res] "=v"(res)
-      : [ad0] "v"(ad0), [ad1] "v"(ad1), [ad2] "v"(ad2), [ad3] "v"(ad3), [iters] "s"(iters), [voff] "v"(voff), [rsrc] "s"(rsrc), [m0v] "s"(m0v)
+      : [ad0] "v"(ad0), [ad1] "v"(ad1), [ad2] "v"(ad2), [ad3] "v"(ad3), [iters] "s"(iters), [voff] "v"(voff), [voffb] "v"(voffb),
+        [rsrc] "s"(rsrc), [m0v] "s"(m0v)
       : %s);
   const unsigned long long t1 = memtime(), r1 = memrealtime();
   if (lane == 0) { atomicMax(&clk[2 * blockIdx.x], t1 - t0); atomicMax(&clk[2 * blockIdx.x + 1], r1 - r0); }
@@ -658,6 +664,9 @@ for (w, mt, nt) in ((8, 2, 5), (4, 4, 5)):
     for (rd, sync, swz) in (("spread", "none", 0), ("spread", "wait", 0), ("spread", "barrier", 0), ("late", "none", 0),
                             ("late", "barrier", 0), ("late", "barrier", 1), ("spread", "barrier", 1), ("spread", "none", 1)):
         tiles.append(kloop_kernel("k_kl%d_%dx%d_%s_%s%s" % (w, mt, nt, rd, sync, "_swz" if swz else ""), w, mt, nt, rd, sync, swz))
+tiles.append(kloop_kernel("k_kl8_2x5_late_barrier_swz_sharedB", 8, 2, 5, "late", "barrier", 1, shared_b=True))
+tiles.append(kloop_kernel("k_kl8_2x5_late_wait_swz_sharedB", 8, 2, 5, "late", "wait", 1, shared_b=True))
+tiles.append(kloop_kernel("k_kl8_2x5_late_wait_swz", 8, 2, 5, "late", "wait", 1))
 attns = [attn_kernel("k_att_product"), attn_kernel("k_att_nobarrier", barrier=False),
          attn_kernel("k_att_nostaging", staging=False), attn_kernel("k_att_nostage_nobar", staging=False, barrier=False),
          attn_kernel("k_att_product_w2", wps=2), attn_kernel("k_att_qk_ahead_w2", order="qk_ahead", wps=2),
