@@ -543,7 +543,8 @@ int cd_dpm_encode(cd_handle h, int net, int sched_kind, const float* x0, const f
                   float* z_out) {
   CD_API_BEGIN
   enter_engine(h);
-  CD_CHECK(h && x0 && coef_host && z_out && B > 0 && K > 0, "bad argument");
+  // K = 0: only x_T is drawn (white_box_steps = -1 of the text wrappers: every decode step then draws fresh noise)
+  CD_CHECK(h && x0 && coef_host && z_out && B > 0 && K >= 0, "bad argument");
   ArenaScope arena_scope(h->arena);
   SamplerState s = setup_sampler(h, net, ctx_c, ctx_uc, ctx_len, guidance, B);
   // the 'ddpm' posterior kernels carry no classifier-free-guidance combine (the pixel DDPMs that use them are unconditional,

@@ -20,6 +20,8 @@ dimension of ONE engine call - same draws, same member o
 import hashlib
 import os
 
+import numpy as np
+
 import torch
 
 from .. import _ffi, schedule
@@ -195,12 +197,15 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
             for enc_scale in self.encoder_unconditional_guidance_scales:
                 for skip in self.skip_steps:
                     K = len(sch) - skip
-                    n_loop = min(K, self.white_box_steps - skip - 1) if self.white_box_steps != -1 else 0
-                    assert n_loop == K, "white_box_steps shorter than the chain is not used by the reference configs"
+                    # the DPM-Encoder loop breaks after white_box_steps - skip - 1 steps (ddim.py:486): the reference's
+                    # configs set white_box_steps = custom_steps (the whole chain, n_loop = K); a shorter prefix leaves the
+                    # rest of the decode to fresh noise (`eps=None`, ddim.py:437), -1 keeps x_T only
+                    n_loop = self._white_box_loop(K, skip)
+                    n_draw = K if n_loop == K else n_loop + 1  # x_T + one per executed step; index 0 draws nothing
                     if self.noise_on_cpu or self.noise_source is not None:
-                        nz = torch.stack([self._randn(tuple(x0.shape)) for _ in range(K)], 0)
+                        nz = torch.stack([self._randn(tuple(x0.shape)) for _ in range(n_draw)], 0)
                     else:
-                        nz = self._randn((K,) + tuple(x0.shape))
+                        nz = self._randn((n_draw,) + tuple(x0.shape))
                     members.append((float(enc_scale), int(skip), nz))
         z_ensemble = [None] * len(members)
         per_call = max(1, self.MAX_FOLD // bsz)
@@ -208,12 +213,22 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
             enc_scale, skip = members[grp[0]][0], members[grp[0]][1]
             for idx in self._chunks(grp, per_call):
                 n = len(idx)
-                z = self.engine.dpm_encode(self.unet, _ffi.CD_SCHED_DDIM, x0.repeat(n, 1, 1, 1), sch.coef_encode(skip),
+                coef, K = sch.coef_encode(skip), len(sch) - skip
+                n_loop = self._white_box_loop(K, skip)
+                if n_loop < K:  # the first n_loop steps of the chain: table rows K-n_loop .. K-1 + the x_T row
+                    coef = np.concatenate([coef[K - n_loop:K], coef[K:K + 1]])
+                z = self.engine.dpm_encode(self.unet, _ffi.CD_SCHED_DDIM, x0.repeat(n, 1, 1, 1), coef,
                                            ctx_c=c.repeat(n, 1, 1), ctx_uc=uc.repeat(n, 1, 1), guidance=enc_scale,
-                                           noise=torch.cat([members[i][2] for i in idx], dim=1), last_uses_x0=True)
+                                           noise=torch.cat([members[i][2] for i in idx], dim=1), last_uses_x0=n_loop == K)
                 for j, i in enumerate(idx):
                     z_ensemble[i] = z[j * bsz:(j + 1) * bsz].reshape(bsz, -1)
         return z_ensemble
+
+    def _white_box_loop(self, K, skip):
+        """DPM-Encoder steps that run for a chain of K steps (ddim.py:486 `if i < white_box_steps - skip_steps - 1`)."""
+        if self.white_box_steps == -1:
+            return 0
+        return max(0, min(K, self.white_box_steps - skip - 1))
 
     # ---- generate (sd_wrapper:142-167)
     def generate(self, z_ensemble, decode_text):
@@ -224,9 +239,20 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
         jobs = []  # (output slot, skip, decoder scale, z) in the reference's order: z member -> decoder scale
         for i, z in enumerate(z_ensemble):
             skip = self.skip_steps[i % len(self.skip_steps)]
-            zz = z.view(bsz, self.white_box_steps - skip, self.channels, self.image_size, self.image_size)
+            slots = self.white_box_steps - skip if self.white_box_steps != -1 else 1  # sd_wrapper:149-152
+            zz = z.view(bsz, slots, self.channels, self.image_size, self.image_size)
+            # decode steps beyond the white-box prefix draw fresh noise (ddim.py:437 `eps=None`): one tensor per step and
+            # candidate, drawn here in candidate order so that folding candidates into one call changes nothing
+            n_tail = (len(sch) - skip) - (slots - 1)
             for j, dec_scale in enumerate(self.decoder_unconditional_guidance_scales):
-                jobs.append((i * n_dec + j, int(skip), float(dec_scale), zz))
+                tail = None
+                if n_tail > 0:
+                    shape = (bsz, self.channels, self.image_size, self.image_size)
+                    if self.noise_on_cpu or self.noise_source is not None:
+                        tail = torch.stack([self._randn(shape) for _ in range(n_tail)], 0)
+                    else:
+                        tail = self._randn((n_tail,) + shape)
+                jobs.append((i * n_dec + j, int(skip), float(dec_scale), zz, tail))
         img_ensemble = [None] * len(jobs)
         per_call = max(1, self.MAX_FOLD // bsz)
 
@@ -248,7 +274,9 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
                 x = self.engine.ddim_decode(self.unet, _ffi.CD_SCHED_DDIM,
                                             torch.cat([jobs[i][3] for i in idx], dim=0).contiguous(),
                                             sch.coef_decode(skip), ctx_c=c.repeat(n, 1, 1), ctx_uc=uc.repeat(n, 1, 1),
-                                            guidance=guidance)
+                                            guidance=guidance,
+                                            noise_tail=None if jobs[idx[0]][4] is None else
+                                            torch.cat([jobs[i][4] for i in idx], dim=1).contiguous())
                 # decode_first_stage, then post_process (x+1)/2 fused into the final layout kernel
                 img = self.engine.vae_decode(self.vae, x, scale=self.SCALE_FACTOR, out_mul=0.5, out_add=0.5)
                 for j, i in enumerate(idx):

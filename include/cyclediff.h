@@ -154,7 +154,10 @@ int cd_vae_decode(cd_handle h, int net, const float* z0, int B, int hlat, float 
  *   noise [K,B,C,H,W] (slot 0 = x_T draw, slots 1..K-1 = per-step draws in loop order) or NULL;
  *   z_out [B,K+1,C,H,W] = stack([x_T, eps_{K-1}, ..., eps_0], dim=1) (sd_wrapper:203).
  *   last_uses_x0: 1 = latent sampler (index 0 returns x0, no draw, ddim.py:583-584);
- *                 0 = pixel wrapper (K-1 ordinary steps; z has K entries). */
+ *                 0 = pixel wrapper (K-1 ordinary steps; z has K entries).
+ *   A white-box prefix shorter than the chain (`white_box_steps` of the text wrappers, ddim.py:486: the loop breaks after
+ *   n < K steps) is the same call on the n + 1 table rows [K-n .. K-1, K] with last_uses_x0 = 0 and n + 1 noise slots - every
+ *   row carries its own timestep; K = 0 draws x_T only (white_box_steps = -1). */
 int cd_dpm_encode(cd_handle h, int net, int sched_kind, const float* x0, const float* ctx_c,
                   const float* ctx_uc, int ctx_len, float guidance, int B, int K,
                   const cd_step_coef* coef_host, const float* noise, uint64_t seed,

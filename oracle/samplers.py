@@ -79,8 +79,9 @@ def latent_encode(eps_model, x0, S, eta, noises, skip_steps=0, white_box_steps=1
     return z
 
 
-def latent_decode(eps_model, x_T, eps_list, S, eta, skip_steps=0, alphas_cumprod=None):
-    """Decode with injected eps; eps_list [B, K, ...]."""
+def latent_decode(eps_model, x_T, eps_list, S, eta, skip_steps=0, alphas_cumprod=None, tail_noises=None):
+    """Decode with injected eps; eps_list [B, n, ...], n <= K: steps beyond the list use fresh noise (`eps=None` in
+    p_sample_ddim_with_eps, ddim.py:437, 640-643), here `tail_noises[i - n]`."""
     ac = sd_alphas_cumprod() if alphas_cumprod is None else alphas_cumprod
     ts, a, a_prev, sig, r = ddim_tables(ac, S, eta)
     K = len(ts) - skip_steps
@@ -92,7 +93,9 @@ def latent_decode(eps_model, x_T, eps_list, S, eta, skip_steps=0, alphas_cumprod
         a_t, a_p, s_t, r_t = _full(B, a[k]), _full(B, a_prev[k]), _full(B, sig[k]), _full(B, r[k])
         e = eps_model(x, t)
         pred_x0 = (x - r_t * e) / a_t.sqrt()
-        x = a_p.sqrt() * pred_x0 + (1. - a_p - s_t ** 2).sqrt() * e + s_t * eps_list[:, i] * 1.0
+        n = eps_list.shape[1] if eps_list is not None else 0
+        inj = eps_list[:, i] if i < n else tail_noises[i - n]
+        x = a_p.sqrt() * pred_x0 + (1. - a_p - s_t ** 2).sqrt() * e + s_t * inj * 1.0
     return x
 
 

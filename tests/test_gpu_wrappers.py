@@ -250,3 +250,55 @@ def test_ldm_text_wrapper_uses_the_posterior_mean(report):
     ps = min(gu.psnr(a.cpu(), b) for a, b in zip(imgs, imgs_ref))
     report.add("wrapper/ldm_text_api", min_psnr_db=ps)
     assert len(imgs) == 4 * len(DEC_SCALES) and ps > PSNR_FLOOR, ps
+
+
+@pytest.mark.parametrize("wb", [12, -1])
+def test_text_wrapper_white_box_prefix_shorter_than_the_chain_vs_oracle(report, wb):
+    """`white_box_steps` below the chain length (ddim.py:486: the DPM-Encoder loop breaks after white_box_steps - skip - 1
+    steps; generate() then views z as [B, white_box_steps - skip, ...] and every decode step beyond the list draws fresh
+    noise, ddim.py:437, 640-643; -1: z = x_T only, sd_wrapper:149-152). No reference config uses it; the engine runs it as
+    the same two calls on a truncated coefficient table. Noise on the CPU in the wrapper's draw order: encode member by
+    member (x_T, then one draw per executed step), decode candidate by candidate (one draw per remaining step)."""
+    image = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(5))
+    src, tgt = ["a photo of a cat", "a red car"], ["a photo of a dog", "a blue car"]
+    scales = [1.0, 3.0]
+    w, emb, usd, vsd = _make(fold=True, white_box_steps=wb, n_trials=1, decoder_unconditional_guidance_scales=scales)
+    torch.manual_seed(78)
+    with torch.no_grad():
+        z_ens = w.encode(image.cuda(), src)
+        imgs = w.generate(z_ens, tgt)
+    # the oracle, composed the same way with the same draws
+    torch.manual_seed(78)
+    with torch.no_grad():
+        mom = nets.vae_encode_moments(vsd, gu.TINY_VAE_CFG, (image - 0.5) * 2.0)
+        x0 = nets.posterior_sample(mom, torch.randn(2, 4, 16, 16)) * 0.18215
+        unet = lambda x, t, c: nets.openai_unet(usd, gu.TINY_SD_CFG, x, t, c)
+        c_src, c_tgt, uc = emb(src), emb(tgt), emb(2 * [""])
+        zs = []
+        for skip in (0, 4):
+            K = STEPS - skip
+            n_loop = 0 if wb == -1 else min(K, wb - skip - 1)
+            nz = [torch.randn(x0.shape) for _ in range(n_loop + 1)]
+            zs.append((skip, n_loop, samplers.latent_encode(samplers.cfg_model(unet, c_src, uc, 1.0), x0, STEPS, 0.1, nz,
+                                                            skip_steps=skip, white_box_steps=wb if wb != -1 else 0)))
+        tails = [[[torch.randn(x0.shape) for _ in range(STEPS - skip - n_loop)] for _g in scales] for skip, n_loop, _ in zs]
+        imgs_ref = []
+        for (skip, n_loop, z), tl in zip(zs, tails):
+            for g, tail in zip(scales, tl):
+                eps = torch.stack(z[1:], 1) if n_loop else None
+                x = samplers.latent_decode(samplers.cfg_model(unet, c_tgt, uc, g), z[0], eps, STEPS, 0.1, skip_steps=skip,
+                                           tail_noises=tail)
+                imgs_ref.append((nets.vae_decode(vsd, gu.TINY_VAE_CFG, x / 0.18215) + 1.0) / 2.0)
+    assert len(z_ens) == 2 and len(imgs) == 4
+    worst_z, min_psnr = 0.0, 1e9
+    for i, (skip, n_loop, zref) in enumerate(zs):
+        assert len(zref) == n_loop + 1 and z_ens[i].shape == (2, (n_loop + 1) * 4 * 16 * 16)
+        zr = torch.stack(zref, 1)
+        got = z_ens[i].view(2, n_loop + 1, 4, 16, 16).cpu()
+        assert torch.allclose(got[:, 0], zr[:, 0], atol=2e-3 * FMT)
+        nr = zr.flatten(2).norm(dim=2)
+        worst_z = max(worst_z, ((got.flatten(2).norm(dim=2) - nr).abs() / nr).max().item())
+    for got, ref in zip(imgs, imgs_ref):
+        min_psnr = min(min_psnr, gu.psnr(got.cpu(), ref))
+    report.add("wrapper/text_api_white_box_%s" % wb, z_norm_rel=worst_z, min_psnr_db=min_psnr)
+    assert worst_z < 2e-3 * FMT and min_psnr > PSNR_FLOOR, (worst_z, min_psnr)

@@ -250,3 +250,53 @@ def test_ranker_scores_a_folded_ensemble_with_texts_and_sources_encoded_once():
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
     assert per_call == {"text": 2 * n * bsz, "image": 2 * n * bsz}
     assert rk.engine.calls == {"text": 2 * bsz, "image": (n + 1) * bsz}
+
+
+@pytest.mark.parametrize("wb", [100, 40, -1])
+def test_white_box_prefix_reaches_the_engine_as_a_truncated_table(wb):
+    """encode() / generate() with `white_box_steps` at, below and without the chain (ddim.py:486; sd_wrapper:149-152) on a
+    recording stand-in for the engine: the DPM-Encoder call gets the first n steps of the chain (table rows K-n .. K-1 by
+    their timesteps + the x_T row, no `index 0 returns x0` special case, n + 1 draws), z has n + 1 slots, and the decode
+    call gets the K - n fresh-noise tensors the steps beyond the prefix consume."""
+    from cycle_diffusion_amd import schedule
+    skip, steps = 20, 99
+    w = object.__new__(_LatentStochasticTextWrapper)
+    torch.nn.Module.__init__(w)
+    w.skip_steps, w.encoder_unconditional_guidance_scales, w.decoder_unconditional_guidance_scales = [skip], [1.0], [3.0]
+    w.n_trials, w.white_box_steps, w.custom_steps, w.eta, w.fold_ensemble = 1, wb, steps, 0.1, True
+    w.channels, w.image_size, w.resolution, w.vae_factor = 4, 2, 16, 8
+    w.noise_on_cpu, w.noise_source = True, None
+    w.alphas_cumprod = schedule.latent_alphas_cumprod(1000, 0.00085, 0.0120)
+    w.cond_stage = lambda texts: torch.zeros(len(texts), 77, 8)
+    w.unet = w.vae = 0
+    w._anchor = torch.nn.Parameter(torch.zeros(1))
+    rec = {}
+
+    class Eng:
+        def vae_encode(self, net, image, **kw):
+            return torch.zeros(image.shape[0], 4, 2, 2)
+
+        def dpm_encode(self, net, kind, x0, coef, noise=None, last_uses_x0=True, **kw):
+            rec["enc"] = (coef.copy(), noise.shape, last_uses_x0)
+            return torch.zeros(x0.shape[0], len(coef), 4, 2, 2)
+
+        def ddim_decode(self, net, kind, z, coef, noise_tail=None, **kw):
+            rec["dec"] = (z.shape, len(coef), None if noise_tail is None else tuple(noise_tail.shape))
+            return z[:, 0].clone()
+
+        def vae_decode(self, net, x, **kw):
+            return x
+
+    w.engine = Eng()
+    K = steps - skip
+    n = K if wb == 100 else (0 if wb == -1 else wb - skip - 1)
+    z = w.encode(torch.rand(1, 3, 16, 16), ["source"])
+    full = w._schedule().coef_encode(skip)
+    coef, nshape, last = rec["enc"]
+    assert len(coef) == n + 1 and nshape[0] == (K if n == K else n + 1) and last == (n == K)
+    t_field = coef.dtype.names[-1]
+    assert list(coef[t_field][:n]) == list(full[t_field][K - n:K])  # the chain's first n steps, by timestep
+    assert z[0].shape == (1, (n + 1) * 4 * 2 * 2)
+    w.generate(z, ["target"])
+    zshape, k_dec, tail = rec["dec"]
+    assert zshape[1] == n + 1 and k_dec == K and tail == (None if n == K else (K - n, 1, 4, 2, 2))
