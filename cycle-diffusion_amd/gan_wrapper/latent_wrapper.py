@@ -13,6 +13,7 @@ Class-conditional models (`enforce_class_input`, cin256) are not used by any ref
 """
 import os
 
+import numpy as np
 import torch
 
 from .. import _ffi, schedule
@@ -97,10 +98,18 @@ class LatentDiffStochasticWrapper(torch.nn.Module):
                                     scale=self.scale_factor)
         sch = schedule.DDIMSchedule(self.alphas_cumprod, self.custom_steps, self.eta)
         K = len(sch)
-        assert self.white_box_steps == K + 1, "the reference configs use white_box_steps = custom_steps + 1"
+        # the DPM-Encoder loop breaks after white_box_steps - 1 steps (latentdiff ddim.py:484, skip_steps = 0): the reference's
+        # configs set white_box_steps = the chain + 1 (n_loop = K); a shorter prefix is the same call on the table rows
+        # K-n_loop .. K-1 + the x_T row (every row carries its timestep) without the `index 0 returns x0` special case
+        n_loop = max(0, min(K, self.white_box_steps - 1))
+        assert self.white_box_steps >= 1 and self.white_box_steps <= K + 1, \
+            "white_box_steps counts x_T and the encoded steps: 1 .. custom chain + 1 (latent_dim is sized by it)"
+        coef = sch.coef_encode()
+        if n_loop < K:
+            coef = np.concatenate([coef[K - n_loop:K], coef[K:K + 1]])
         # draw order of _ddpm_ddim_encoding: randn_like(x0), then one randn per sample_xt_next except index 0
-        nz = self._randn(K, tuple(x0.shape))
-        z = self.engine.dpm_encode(self.unet, _ffi.CD_SCHED_DDIM, x0, sch.coef_encode(), noise=nz, last_uses_x0=True)
+        nz = self._randn(K if n_loop == K else n_loop + 1, tuple(x0.shape))
+        z = self.engine.dpm_encode(self.unet, _ffi.CD_SCHED_DDIM, x0, coef, noise=nz, last_uses_x0=n_loop == K)
         z = z.view(x0.shape[0], -1)
         assert z.shape[1] == self.latent_dim
         return z
@@ -109,7 +118,9 @@ class LatentDiffStochasticWrapper(torch.nn.Module):
         bsz = z.shape[0]
         zz = z.view(bsz, self.white_box_steps, self.channels, self.image_size, self.image_size).contiguous()
         sch = schedule.DDIMSchedule(self.alphas_cumprod, self.custom_steps, self.eta)
-        x = self.engine.ddim_decode(self.unet, _ffi.CD_SCHED_DDIM, zz, sch.coef_decode())
+        n_tail = len(sch) - (self.white_box_steps - 1)  # decode steps beyond the list draw fresh noise (ddim.py:436)
+        tail = self._randn(n_tail, (bsz, self.channels, self.image_size, self.image_size)) if n_tail > 0 else None
+        x = self.engine.ddim_decode(self.unet, _ffi.CD_SCHED_DDIM, zz, sch.coef_decode(), noise_tail=tail)
         if self.refine_steps > 0:  # convsample_ddim: refine with eta = 1 (latentdiff_stochastic_wrapper.py:70-78)
             rs = schedule.DDIMSchedule(self.alphas_cumprod, self.custom_steps, 1.0)
             nz = self._randn(self.refine_steps + 1, tuple(x.shape))

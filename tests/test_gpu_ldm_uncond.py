@@ -232,3 +232,31 @@ def test_ema_shadow_weights_are_what_the_unet_runs_on():
     with pytest.raises(KeyError):
         LatentDiffStochasticWrapper("celeba256", state_dict={k: v for k, v in ckpt.items()
                                                             if not k.startswith("model_ema.")}, **kw)
+
+
+def test_latentdiff_wrapper_white_box_prefix_is_the_truncated_chain():
+    """`white_box_steps` below the chain + 1 (latentdiff ddim.py:484: the DPM-Encoder loop breaks after white_box_steps - 1
+    steps; :436: decode steps beyond the list draw fresh noise). The engine runs it on a truncated coefficient table, so with
+    the same draws (a) the short z is, bit for bit, the head of the full chain's z and (b) decoding it equals decoding the
+    full-length list whose missing slots hold the fresh-noise tensors (an injected eps and a drawn noise enter a step the
+    same way: sigma_t * eps, ddim.py:640-643)."""
+    fx = gu.load("ldm_uncond_tiny")
+    S, wb = int(fx["steps"]), 21
+    image = torch.rand((1, 3, 64, 64), generator=torch.Generator().manual_seed(int(fx["img_seed"])))
+    w_full, _ = _wrapper(fx, 0)
+    w_short, _ = _wrapper(fx, 0)
+    w_short.white_box_steps = wb
+    w_short.latent_dim = 16 * 16 * 3 * wb
+    with torch.no_grad():
+        torch.manual_seed(11)
+        z_full = w_full.encode(image.cuda()).view(1, S + 1, 3, 16, 16)
+        torch.manual_seed(11)
+        z_short = w_short.encode(image.cuda())
+        assert z_short.shape == (1, w_short.latent_dim)
+        assert torch.equal(z_short.view(1, wb, 3, 16, 16), z_full[:, :wb])
+        torch.manual_seed(12)
+        img_short = w_short(z_short)
+        torch.manual_seed(12)
+        tail = torch.stack([torch.randn(1, 3, 16, 16) for _ in range(S + 1 - wb)], 1).cuda()
+        img_cat = w_full(torch.cat([z_short.view(1, wb, 3, 16, 16), tail], dim=1).reshape(1, -1))
+    assert torch.isfinite(img_short).all() and torch.equal(img_short, img_cat)
