@@ -95,6 +95,17 @@ int main(int argc, char** argv) {
     printf("attn B%d Tq%d Tk%d H%d d%d %s: %.3f ms per call incl. layout conversions (%.0f GFLOP of attention); o[0..3] = %g %g %g %g\n",
            B, T, Tk, H, D, vt ? "V^T" : "V token-major", ms / iters, 4.0 * B * H * (double)T * Tk * D * 1e-9, ho[0], ho[1], ho[2],
            ho[3]);
+    // whole-output fingerprint (torch-free A/B of kernel variants: identical bits <=> identical xor / sums)
+    std::vector<float> all(nq);
+    HIP_OK(hipMemcpy(all.data(), o, nq * sizeof(float), hipMemcpyDeviceToHost));
+    unsigned long long x = 0; double s1 = 0, s2 = 0; size_t bad = 0;
+    for (size_t i = 0; i < nq; ++i) {
+      unsigned u; memcpy(&u, &all[i], 4);
+      x = (x << 1 | x >> 63) ^ u;
+      if (!(all[i] == all[i]) || fabsf(all[i]) > 3e38f) { ++bad; continue; }
+      s1 += all[i]; s2 += (double)all[i] * all[i];
+    }
+    printf("attn output fingerprint: rolling xor %016llx  sum %.9g  sum of squares %.9g  non-finite %zu\n", x, s1, s2, bad);
   } else {
     fprintf(stderr, "unknown mode %s\n", argv[1]);
     return 2;
