@@ -8,8 +8,10 @@ towards the target text with classifier-free guidance 3 -> VAE decode -> (x + 1)
 the same triplet through their reference API (encode / __call__) on the same weights (rebuilt from the (name, shape)
 lists in the fixture), the same contexts and the same CPU-drawn noise.
 
-Stated tolerance: image PSNR >= 35 dB vs the reference image (images in [0, 1],
-evaluation/utils.py:60-67); the latent, x_T and the extracted eps slots are compared as well and reported."""
+Stated tolerance: image PSNR >= 50 dB (fp16 build; 34 dB for the bf16 build) vs the reference image
+(images in [0, 1], evaluation/utils.py:60-67) - measured 53.6-55.6 dB over rounds 2-4, so a regression of a factor of two
+in error fails; the latent, x_T and the extracted eps slots are compared as well and reported. Folded batches are checked
+in EVERY slot (round 4 found samples 16+ of a folded VAE decode reading zeros while a one-slot check stayed green)."""
 import json
 import os
 import warnings
@@ -27,7 +29,12 @@ from oracle import nets
 pytestmark = pytest.mark.gpu
 
 FMT = 1.0 if _ffi.load_library().cd_act_format() == 1 else 8.0
-PSNR_FLOOR = 35.0 if FMT == 1.0 else 32.0  # bf16 build: measured 36.1-37.4 dB (profiles/r3_parity_e2e_bf16_build.json)
+# fp16 build: measured 53.6-55.6 dB (C2 / C3, alone and folded) and 54.1-59.1 dB (ensemble candidates) over rounds 2-4;
+# bf16 build: 35.9-37.4 dB (profiles/r4_parity_e2e_bf16_build.json)
+PSNR_FLOOR = 50.0 if FMT == 1.0 else 34.0
+# 99-step encode -> decode self-cycle of the 16-bit engine on a unit-variance latent, (rms bound, max bound) per fixture:
+# measured rms 0.016-0.020 (C2) / 0.029-0.032 (C3), max 0.095-0.16 over the builds of rounds 2-4
+CYCLE_BOUNDS = {"c2_sd512_e2e": (0.025, 0.2), "c3_ldm256_e2e": (0.045, 0.2)}
 
 
 class SeededEmbedder:
@@ -105,10 +112,10 @@ def _run(cls, fx_name, res, ctx_dim, report):
     # 99-step self-cycle at full size on a random-init 860 M-parameter network (the fp32 reference closes it to 1.6e-5,
     # SURVEY.md 8c; a 16-bit engine re-quantises x_t every step). The chain is chaotic in its low bits: over six
     # builds of round 2 the rms error was 0.017-0.020 (C2) / 0.029-0.032 (C3) of a unit-variance latent, the maximum
-    # over 16 K / 4 K elements 0.11-0.16. The rms is the stable figure and carries the bound (2x); the maximum gets
-    # the same factor.
-    assert cyc.pow(2).mean().sqrt().item() < 0.065 * FMT, cyc.pow(2).mean().sqrt().item()
-    assert cyc.max().item() < 0.32 * FMT, cyc.max().item()
+    # over 16 K / 4 K elements 0.11-0.16. Bounds (CYCLE_BOUNDS): 1.25-1.4x the largest rms seen, 0.2 for the maximum.
+    rms_bound, max_bound = CYCLE_BOUNDS[fx_name]
+    assert cyc.pow(2).mean().sqrt().item() < rms_bound * FMT, cyc.pow(2).mean().sqrt().item()
+    assert cyc.max().item() < max_bound * FMT, cyc.max().item()
     return p
 
 
@@ -186,7 +193,7 @@ def test_c2_ensemble_members_skips_and_scales_vs_reference(report):
     c2_sd_ensemble256_e2e.npz holds the reference's own DDIMSampler runs, one member at a time with the wrapper's
     arguments (oracle/gen_golden_full.py:gen_c2_ensemble); here the drop-in wrapper produces all of them through
     encode() / generate() with the members that share (skip, scale) FOLDED into one batch of 2. Every candidate is
-    held to the 35 dB floor; member order, x_T and the latent norms are checked too."""
+    held to PSNR_FLOOR (measured 54.1-59.1 dB); member order, x_T and the latent norms are checked too."""
     from cycle_diffusion_amd.engine import sd_v1_unet_desc
     path = os.path.join(gu.GOLD, "c2_sd_ensemble256_e2e.npz")
     if not os.path.exists(path):
@@ -264,9 +271,16 @@ class _ListEmbedder:
 
 def _folded(report, cls, model_type, fx_name, res, ctx_dim, B, slot, tag):
     """The fixture's triplet as sample `slot` of a B-batch whose other triplets are different images / texts / noise
-    streams: its image must match the REFERENCE's (>= 35 dB, the same floor as at B = 1) and its own B = 1 result
-    (>= 45 dB: tile choices never change a bit, split-K factors and the streaming / tile kernel choice change fp32
-    summation order, which the 198-step chain amplifies)."""
+    streams. EVERY slot of the batch is checked (round 4: samples 16+ of a folded first-stage decode read zeros for two
+    rounds while a one-slot check stayed green):
+      * the fixture's slot against the REFERENCE's image (the B = 1 floor) and against its own B = 1 result;
+      * slots 0, 15, 16, B - 1 (either side of the 2 GiB boundary of the first-stage decoder, and the ends) against THEIR
+        B = 1 runs: >= 45 dB each (tile choices never change a bit; split-K factors and the streaming / tile kernel choice
+        change fp32 summation order, which the 198-step chain amplifies);
+      * every slot's image against the first-stage decode of ITS OWN target latent at batch 1 (the latents the wrapper
+        handed to vae_decode are recorded): >= 50 dB - a slot decoded from zeros, from a neighbour's latent or from a
+        wrapped offset fails this by tens of dB;
+      * every slot's target latent differs from every other slot's (no duplicated or dropped samples)."""
     path = os.path.join(gu.GOLD, fx_name + ".npz")
     if not os.path.exists(path):
         pytest.skip("fixture not generated")
@@ -290,28 +304,65 @@ def _folded(report, cls, model_type, fx_name, res, ctx_dim, B, slot, tag):
     tgt = ["seed:%d" % (seeds["c_tgt"] if b == slot else 3000 + b) for b in range(B)]
     nz_seeds = [seeds["noise"] if b == slot else 4000 + b for b in range(B)]
     images = torch.cat([torch.rand((1, 3, res, res), generator=torch.Generator().manual_seed(s)) for s in img_seeds], 0)
+    latents = []  # what the wrapper hands to the first-stage decoder, call by call
+    real_decode = w.engine.vae_decode
+
+    def recording_decode(net, x, **kw):
+        latents.append(x.detach().clone())
+        return real_decode(net, x, **kw)
 
     def run(sel):
         w.noise_source = _PerSampleNoise([nz_seeds[b] for b in sel])
-        with torch.no_grad():
-            x = images[sel].cuda()
-            z = w.encode(x, [src[b] for b in sel])
-            return w(z, x, [src[b] for b in sel], [tgt[b] for b in sel]).cpu(), z[0].cpu()
+        del latents[:]
+        w.engine.vae_decode = recording_decode
+        try:
+            with torch.no_grad():
+                x = images[sel].cuda()
+                z = w.encode(x, [src[b] for b in sel])
+                out = w(z, x, [src[b] for b in sel], [tgt[b] for b in sel]).cpu()
+        finally:
+            w.engine.vae_decode = real_decode
+        assert len(latents) == 1 and latents[0].shape[0] == len(sel)  # ONE first-stage call for the whole batch
+        return out, z[0].cpu(), latents[0]
 
-    imgB, zB = run(list(range(B)))
-    img1, z1 = run([slot])
+    imgB, zB, latB = run(list(range(B)))
+    assert imgB.shape[0] == B and torch.isfinite(imgB).all()
     ref = torch.as_tensor(fx["img"])
-    p_ref, p_ref1 = gu.psnr(imgB[slot:slot + 1], ref), gu.psnr(img1, ref)
-    p_self = gu.psnr(imgB[slot:slot + 1], img1)
-    zd = (zB[slot] - z1[0]).abs().max().item()
-    others_finite = bool(torch.isfinite(imgB).all())
+    # ---- spread slots (and the fixture's) against their own B = 1 runs
+    spread = sorted({0, 15, 16, B - 1, slot} & set(range(B)))
+    p_alone, z_alone = {}, {}
+    for b in spread:
+        img1, z1, _ = run([b])
+        p_alone[b] = gu.psnr(imgB[b:b + 1], img1)
+        z_alone[b] = (zB[b] - z1[0]).abs().max().item()
+        if b == slot:
+            p_ref1 = gu.psnr(img1, ref)
+            img_slot_alone = img1
+    p_ref = gu.psnr(imgB[slot:slot + 1], ref)
+    # ---- every slot: the batch's image against the first-stage decode of that slot's own latent at batch 1
+    p_vae = []
+    with torch.no_grad():
+        for b in range(B):
+            one = real_decode(w.vae, latB[b:b + 1].contiguous(), scale=w.SCALE_FACTOR, out_mul=0.5, out_add=0.5).cpu()
+            p_vae.append(gu.psnr(imgB[b:b + 1], one))
+    # ---- no two slots carry the same target latent
+    flat = latB.flatten(1).float().cpu()
+    gram = torch.cdist(flat, flat) / flat.shape[1] ** 0.5  # rms distance between latents
+    gram.fill_diagonal_(float("inf"))
+    min_dist = gram.min().item()
     report.add("e2e/" + tag, psnr_vs_reference_in_batch=p_ref, psnr_vs_reference_alone=p_ref1,
-               psnr_batch_vs_alone=p_self, z_maxabs_batch_vs_alone=zd, batch=B,
-               img_maxabs_batch_vs_alone=(imgB[slot:slot + 1] - img1).abs().max().item())
-    assert others_finite
+               psnr_batch_vs_alone=p_alone[slot], psnr_batch_vs_alone_by_slot={str(b): p_alone[b] for b in spread},
+               z_maxabs_batch_vs_alone=z_alone[slot], batch=B,
+               img_maxabs_batch_vs_alone=(imgB[slot:slot + 1] - img_slot_alone).abs().max().item(),
+               psnr_batch_image_vs_own_latent_decoded_alone_min=min(p_vae),
+               psnr_batch_image_vs_own_latent_decoded_alone_argmin=int(np.argmin(p_vae)),
+               latent_rms_distance_between_slots_min=min_dist)
     assert p_ref >= PSNR_FLOOR and p_ref1 >= PSNR_FLOOR, (p_ref, p_ref1)
-    assert p_self >= (45.0 if FMT == 1.0 else 25.0), p_self
-    # the other samples are different triplets, not copies
+    floor_self = 45.0 if FMT == 1.0 else 25.0
+    assert min(p_alone.values()) >= floor_self, p_alone
+    assert min(p_vae) >= (50.0 if FMT == 1.0 else 40.0), p_vae
+    # the other samples are different triplets, not copies (unit-variance latents: independent samples are ~1.4 apart)
+    assert min_dist > 0.1, min_dist
     assert (imgB[0] - imgB[slot]).abs().mean().item() > 1e-3
 
 
@@ -374,7 +425,11 @@ def test_c2_ensemble_decode_call_of_25_members_vs_members_alone(report):
     report.add("e2e/c2_ensemble_call_of_25_vs_alone", psnr_db_min=min(ps), psnr_db_max=max(ps), psnr_db=ps,
                member_spread_min=spread)
     assert all(torch.isfinite(x).all() for x in folded)
-    assert min(ps) >= (45.0 if FMT == 1.0 else 25.0), ps
+    floor = 45.0 if FMT == 1.0 else 25.0
+    assert min(ps) >= floor, ps
+    # members 16 .. 24 explicitly: their rows lie beyond the 2 GiB boundary of the 512 x 512 first-stage decoder (the bug
+    # this test found in round 4 left exactly these members decoded from zeros)
+    assert len(ps[16:]) == 9 and min(ps[16:]) >= floor, ps[16:]
     assert spread > 1e-3
 
 
