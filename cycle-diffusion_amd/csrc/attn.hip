@@ -30,6 +30,8 @@
 //   * the ragged last tile alone is masked, P is packed with one convert per pair and - where V^T has a
 //     spare padded row - the row sums fall out of the PV MFMA itself.
 // fp32 softmax statistics and accumulation, 16-bit operands.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -360,6 +362,234 @@ __global__ __launch_bounds__(64 * NWV, DV <= 96 ? (KG == 32 ? (DV <= 64 ? 4 : 3)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// d = 40 self-attention over long sequences (the 320-channel level of the SD / LDM U-Nets: 4096 / 1024 tokens, 8 heads;
+// attention.py:171-200) - round 5. Same algorithm and the same numerics as k_attention<48, 64, 40, 2, false, 32, 8> above
+// (S^T = K Q^T with -m as the C operand, deferred maximum, ones row for the denominators, V^T pre-transposed in HBM), with
+// three changes to what a 64-key tile costs:
+//   * K and V^T tiles go HBM / L2 -> LDS by `buffer_load_dwordx4 ... lds` (as conv_gemm.hip stages its operands): no
+//     staging registers, no ds_write, 13 wave-wide copies per tile and workgroup instead of 16 loads + 24 LDS stores.
+//     LDS rows are 128 bytes with the 16-byte chunks XOR-swizzled on the SOURCE side (chunk c of row r sits at
+//     c ^ ((r >> 1) & 7)): every fragment read below is the conflict-free ds_read_b128 pattern of conv_gemm.hip's BK = 64
+//     tiles. The zero padding of K (d 40 .. 47) arrives as the zeros of an out-of-range offset.
+//   * the K rows of a tile are gathered in PERMUTED key order - the two middle 4-row pieces of every 16 rows swapped - so
+//     that the 8 probabilities a lane feeds to one PV MFMA (accumulator rows {0-3, 8-11} + 4 half of S^T) belong to 8
+//     CONSECUTIVE keys: V^T is then read in its natural order (one aligned 16-byte read per fragment) and needs no
+//     permuted copy.
+//   * rows 32 .. 47 of O^T (d 32 .. 39, the ones row 40, 7 padding rows) are a 16-row block on v_mfma_f32_16x16x32 instead
+//     of a second 32-row block: the P operand of the 16 x 16 form (lane = query n & 15, k group lane >> 4) comes out of the
+//     32 x 32 layout by one v_permlane16_swap per register pair - X = keys 0 .. 15, Y = keys 16 .. 31 of the group:
+//     swap(X, Y) leaves queries 0 .. 15 with the four k groups [X.h0 | Y.h0 | X.h1 | Y.h1] in X and queries 16 .. 31 in Y.
+//     Matrix work per 32-key group: 3 (QK^T) + 2 (PV rows 0 .. 31) + 2 x 1/2 (rows 32 .. 47) = 6 instead of 7 32 x 32 x 16
+//     equivalents, one LDS fragment read less, 8 accumulator registers less.
+// 8 waves x 32 queries per workgroup, two LDS buffers, one barrier per tile.
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV, 4) void k_attention_d40(AttnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(NWV == 8, "one K copy per wave and tile");
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  constexpr int D = 40, NKS = 3, ROWB = 128;
+  constexpr int KBUF = KT * ROWB;   // K tile: [64 keys (permuted)][64 x 16 bit]: d 0 .. 39 | zeros
+  constexpr int VBUF = 48 * ROWB;   // V^T tile: [48 d rows][64 keys]: rows 0 .. 39 data, row 40 ones, 41 .. 47 zeros
+  constexpr int BUF = KBUF + VBUF;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qi = lane & 31, half = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * (32 * NWV) + wave * 32;
+
+  const bf16_t* qb = p.q + (int64_t)b * p.q_bs + h * D;
+  const bf16_t* kb = p.k + (int64_t)b * p.k_bs + h * D;
+  const bf16_t* vtb = p.vt + ((int64_t)b * p.H + h) * (int64_t)p.vt_dpad * p.vt_tpad;
+
+  // Q fragments (B operand of S^T = K Q^T): lane holds Q[q][ks * 16 + 8 half .. + 7] in log2 score units
+  bf16x8 qf[NKS];
+  {
+    const float qsc = p.scale * 1.44269504088896340736f;
+    const int q = q0 + qi;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int d0 = ks * 16 + 8 * half;
+      uint4 raw = make_uint4(0, 0, 0, 0);
+      if (q < p.Tq && d0 < D) raw = *(const uint4*)(qb + (int64_t)q * p.ldq + d0);
+      if (!p.q_log2) {
+        float f[8];
+        unpack8(raw, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= qsc;
+        raw = pack8(f);
+      }
+      qf[ks] = *(bf16x8*)&raw;
+    }
+  }
+
+  // ---- copy geometry: one wave-wide copy = 8 LDS rows x 128 B; lane l fills physical chunk l & 7 of row 8 x + (l >> 3)
+  // from logical chunk (l & 7) ^ ((row >> 1) & 7). K: copy `wave` of 8; V^T: waves 0 .. 4 (d rows 0 .. 39).
+  constexpr unsigned kNoLoad = 0x80000000u;
+  const unsigned k_bytes = p.Tk > 0 ? (unsigned)(((int64_t)(p.Tk - 1) * p.ldk + D) * 2) : 0u;
+  const unsigned v_bytes = (unsigned)((int64_t)p.vt_dpad * p.vt_tpad * 2);
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vtb, 0, v_bytes, 0x00020000);
+  unsigned k_voff, v_voff;
+  {
+    const int row = 8 * wave + (lane >> 3);
+    const int lc = (lane & 7) ^ ((row >> 1) & 7);
+    const int pc = (row >> 2) & 3;                                             // 4-row piece within its 16 rows
+    const int key = (row & ~12) | ((((pc & 1) << 1) | (pc >> 1)) << 2);        // pieces [0 2 1 3]
+    k_voff = lc < D / 8 ? (unsigned)((key * p.ldk + lc * 8) * 2) : kNoLoad;    // chunks 5 .. 7: zeros
+    v_voff = (row < D && row < p.vt_dpad) ? (unsigned)((row * p.vt_tpad + lc * 8) * 2) : kNoLoad;
+  }
+  auto fetch = [&](int key0, int buf) {
+    // the tile position is added to the VECTOR offset: the descriptor's bounds check (rows beyond Tk -> zeros) covers it only
+    char* kd = lds + buf * BUF + wave * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lptr_t)kd, 16, k_voff + (unsigned)(key0 * p.ldk * 2), 0, 0, 0);
+    if (wave < D / 8)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lptr_t)(kd + KBUF), 16, v_voff + (unsigned)(key0 * 2), 0, 0, 0);
+  };
+  // rows 40 .. 47 of both V^T buffers are never copied over: the ones row and its padding, written once
+  if (wave == 5 || wave == 6) {
+    const uint4 v = lane < 8 ? make_uint4(kOnePair, kOnePair, kOnePair, kOnePair) : make_uint4(0, 0, 0, 0);
+    *(uint4*)(lds + (wave - 5) * BUF + KBUF + D * ROWB + lane * 16) = v;
+  }
+
+  // ---- fragment read offsets (bytes inside a buffer)
+  const int sw = (qi >> 1) & 7;                    // rows qi and 32 + qi share it: (32 >> 1) & 7 == 0
+  const int kf_off = qi * ROWB;                    // + 32 ROWB per key half; chunk (2 ks + half) ^ sw
+  const int vf_off = KBUF + qi * ROWB;             // chunk (4 g + 2 s2 + half) ^ sw
+  const int tm = lane & 15, tg = lane >> 4;        // 16 x 16 x 32 A operand: d row 32 + tm, k group tg = keys [0 2 1 3][tg] * 8
+  const int vt_off = KBUF + (32 + tm) * ROWB;
+  const int vt_sw = ((32 + tm) >> 1) & 7, vt_lc = ((tg & 1) << 1) | (tg >> 1);
+
+  f32x16 o0;
+  f32x4 ot0 = {0.f, 0.f, 0.f, 0.f}, ot1 = {0.f, 0.f, 0.f, 0.f};
+  f32x16 negm;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; negm[r] = 0.f; }
+  constexpr float kDefer = 8.0f;
+
+  const int ntiles = (p.Tk + KT - 1) / KT;
+  fetch(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int key0 = t * KT;
+    const int buf = t & 1;
+    if (t + 1 < ntiles) fetch(key0 + KT, buf ^ 1);
+    const char* Bt = lds + buf * BUF;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      // ---- S^T - m = K Q^T - m over the 32 (permuted) keys of this group
+      f32x16 s;
+      {
+        bf16x8 kf[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+          kf[ks] = *(const bf16x8*)(Bt + kf_off + g * 32 * ROWB + (((2 * ks + half) ^ sw) << 4));
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) s = CD_MFMA_32x32x16(kf[ks], qf[ks], ks == 0 ? negm : s);
+      }
+      if (key0 + KT > p.Tk || p.causal) {
+        const int kmax = p.causal ? min(p.Tk - 1, q0 + qi) : p.Tk - 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;  // LDS row of the group -> key through the piece swap
+          const int pc = (row >> 2) & 3;
+          const int key = key0 + g * 32 + ((row & ~12) | ((((pc & 1) << 1) | (pc >> 1)) << 2));
+          s[r] = key <= kmax ? s[r] : -INFINITY;
+        }
+      }
+      // group maximum relative to m (the chain starts with a compiler-visible read of the last MFMA's result: see above)
+      float mx = __builtin_amdgcn_fmed3f(s[14], s[15], INFINITY);
+#pragma unroll
+      for (int r = 0; r < 14; r += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[r]), "v"(s[r + 1]));
+      const bool first = t == 0 && g == 0;
+      if (first || __any(mx > kDefer)) {
+        const float mxq = fmaxf(mx, __shfl_xor(mx, 32));
+        float delta = first ? mxq : fmaxf(mxq, 0.f);
+        delta = delta == -INFINITY ? 0.f : delta;
+        const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] -= delta; negm[r] -= delta; o0[r] *= alpha; }
+        // the 16-row block holds query (lane & 15) + 16 qh in every lane: its factor lives in lane (lane & 15) + 16 qh
+        const float a0 = __shfl(alpha, lane & 15), a1 = __shfl(alpha, 16 + (lane & 15));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ot0[r] *= a0; ot1[r] *= a1; }
+      }
+      uint32_t pw[8];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2)
+        pw[r >> 1] = pack2_prob(__builtin_amdgcn_exp2f(s[r]), __builtin_amdgcn_exp2f(s[r + 1]));
+      // ---- O^T rows 0 .. 31 += V^T P^T (two 16-key slices)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 vf = *(const bf16x8*)(Bt + vf_off + (((4 * g + 2 * s2 + half) ^ sw) << 4));
+        const uint4 praw = make_uint4(pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]);
+        o0 = CD_MFMA_32x32x16(vf, __builtin_bit_cast(bf16x8, praw), o0);
+      }
+      // ---- rows 32 .. 47: P^T regrouped for the 16 x 16 x 32 form, one A fragment for both query halves
+      {
+        uint32_t xa[4], ya[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const auto r2 = __builtin_amdgcn_permlane16_swap(pw[i], pw[4 + i], false, false);
+          xa[i] = r2[0]; ya[i] = r2[1];
+        }
+        const bf16x8 va = *(const bf16x8*)(Bt + vt_off + (((4 * g + vt_lc) ^ vt_sw) << 4));
+        ot0 = CD_MFMA_16x16x32(va, __builtin_bit_cast(bf16x8, make_uint4(xa[0], xa[1], xa[2], xa[3])), ot0);
+        ot1 = CD_MFMA_16x16x32(va, __builtin_bit_cast(bf16x8, make_uint4(ya[0], ya[1], ya[2], ya[3])), ot1);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's copies of the next tile have landed
+    __syncthreads();                                   // ... everyone's; and everyone is done reading this tile
+  }
+
+  // ---- normalise and store. Denominators: row d = 40 of O^T = register 0 of lanes 32 .. 47 of the 16-row blocks
+  const float l0 = __shfl(ot0[0], 32 + (lane & 15)), l1 = __shfl(ot1[0], 32 + (lane & 15));
+  {
+    const int q = q0 + qi;
+    const float inv = 1.0f / ((qi & 16) ? l1 : l0);
+    if (q < p.Tq) {
+      bf16_t* ob = p.o + (int64_t)b * p.o_bs + (int64_t)q * p.ldo + h * D;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int d0 = 8 * rq + 4 * half;
+        float bb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.obias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bb[e] = p.obias[h * D + d0 + e];
+        }
+        uint2 pk;
+        pk.x = pack2(o0[rq * 4 + 0] * inv + bb[0], o0[rq * 4 + 1] * inv + bb[1]);
+        pk.y = pack2(o0[rq * 4 + 2] * inv + bb[2], o0[rq * 4 + 3] * inv + bb[3]);
+        *(uint2*)(ob + d0) = pk;
+      }
+    }
+  }
+  if (tg < 2) {  // d 32 .. 39: lane holds d = 32 + 4 tg + r of query tm (+ 16)
+    const int d0 = 32 + 4 * tg;
+    float bb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.obias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bb[e] = p.obias[h * D + d0 + e];
+    }
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {
+      const int q = q0 + tm + 16 * qh;
+      const f32x4 ov = qh ? ot1 : ot0;
+      const float inv = 1.0f / (qh ? l1 : l0);
+      if (q < p.Tq) {
+        uint2 pk;
+        pk.x = pack2(ov[0] * inv + bb[0], ov[1] * inv + bb[1]);
+        pk.y = pack2(ov[2] * inv + bb[2], ov[3] * inv + bb[3]);
+        *(uint2*)(p.o + (int64_t)b * p.o_bs + (int64_t)q * p.ldo + h * D + d0) = pk;
+      }
+    }
+  }
+#endif
+}
+
 // V [B][Tk][ldv] -> Vt [B][H][Dpad][Tpad]; grid (Tpad/64, H, B)
 __global__ __launch_bounds__(256) void k_transpose_v(const bf16_t* __restrict__ v, int ldv, int64_t v_bs,
                                                      bf16_t* __restrict__ vt, int H, int Tk, int D,
@@ -432,8 +662,14 @@ void launch_attention(hipStream_t st, const AttnParams& p) {
     }
 #undef CD_ATTN_DBG_CASE
 #endif
-    hipLaunchKernelGGL((k_attention<48, 64, 40, 2, false, 32, 8>), dim3(ceil_div(p.Tq, 256), p.H, p.B), dim3(512), 0, st,
-                       p);
+    // round 5: the LDS-DMA / 16-row-block form (k_attention_d40); CD_ATTN_D40=0 selects the round-3 kernel for A/B runs
+    static const bool d40_new = [] { const char* e = getenv("CD_ATTN_D40"); return !(e && e[0] == '0'); }();
+    if (d40_new && p.vt_dpad >= 40 && (p.ldk % 8) == 0 && (p.vt_tpad % 8) == 0 &&
+        (int64_t)p.Tk * p.ldk * 2 < (1ll << 31) && (int64_t)p.vt_dpad * p.vt_tpad * 2 < (1ll << 31))
+      hipLaunchKernelGGL((k_attention_d40<8>), dim3(ceil_div(p.Tq, 256), p.H, p.B), dim3(512), 0, st, p);
+    else
+      hipLaunchKernelGGL((k_attention<48, 64, 40, 2, false, 32, 8>), dim3(ceil_div(p.Tq, 256), p.H, p.B), dim3(512), 0, st,
+                         p);
   } else if (p.D == 40 && half_groups) CD_ATTN_KG(48, 64, 40, 2, 32);
   else if (p.D == 40) CD_ATTN(48, 64, 40, 2);
   else if (p.D == 80 && half_groups) CD_ATTN_KG(80, 96, 80, 2, 32);  // 640-channel level: three waves per SIMD

@@ -506,8 +506,10 @@ int cd_vae_encode(cd_handle h, int net, const float* img, const float* noise, ui
   ArenaScope arena_scope(h->arena);
   Ctx c = h->ctx();
   const int cin = v->desc.in_channels, cp = round_up(cin, 32), hl = R / v->factor;
-  bf16_t* xin = (bf16_t*)h->arena.alloc((size_t)B * R * R * cp * 2);
-  launch_nchw_to_nhwc(h->st, img, xin, B, cin, R * R, cp, 1.f, 0.f, 0);
+  // 16-bit rows, or - first stage in fp32 / in the split mode - fp32 rows / fp16 pairs (the same bytes)
+  bf16_t* xin = (bf16_t*)h->arena.alloc((size_t)B * R * R * cp * (v->f32 ? 4 : 2));
+  if (v->f32) launch_nchw_to_nhwc_f32(h->st, img, (float*)xin, B, cin, R * R, cp, 1.f, 0.f, v->x3 ? 1 : 0, h->overflow_dev);
+  else launch_nchw_to_nhwc(h->st, img, xin, B, cin, R * R, cp, 1.f, 0.f, 0);
   const int mch = v->moments_channels;
   float* mom = (float*)h->arena.alloc((size_t)B * hl * hl * mch * 4);
   v->encode_moments(c, xin, B, R, mom);
@@ -526,9 +528,11 @@ int cd_vae_decode(cd_handle h, int net, const float* z0, int B, int hlat, float 
   ArenaScope arena_scope(h->arena);
   Ctx c = h->ctx();
   const int zc = v->desc.embed_dim, cp = round_up(zc, 32), R = hlat * v->factor, co = v->desc.out_channels;
-  bf16_t* zin = (bf16_t*)h->arena.alloc((size_t)B * hlat * hlat * cp * 2);
+  bf16_t* zin = (bf16_t*)h->arena.alloc((size_t)B * hlat * hlat * cp * (v->f32 ? 4 : 2));
   if (v->codebook)  // VQModelInterface.decode: quantise to the codebook first (autoencoder.py:274-280)
     launch_vq_quantize(h->st, z0, 1.0f / scale, v->codebook, v->n_embed, zc, B, hlat * hlat, zin, cp);
+  else if (v->f32)
+    launch_nchw_to_nhwc_f32(h->st, z0, (float*)zin, B, zc, hlat * hlat, cp, 1.0f / scale, 0.f, v->x3 ? 1 : 0, h->overflow_dev);
   else
     launch_nchw_to_nhwc(h->st, z0, zin, B, zc, hlat * hlat, cp, 1.0f / scale, 0.f, 0);  // z = 1/scale * z (ddpm.py:705)
   float* o = (float*)h->arena.alloc((size_t)B * R * R * co * 4);

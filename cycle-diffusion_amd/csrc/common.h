@@ -52,6 +52,8 @@ __device__ inline void unpack8(const uint4& raw, float* f) {
 }
 #define CD_MFMA_32x32x16(a, b, c) \
   __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(::cd::f16x8, a), __builtin_bit_cast(::cd::f16x8, b), c, 0, 0, 0)
+#define CD_MFMA_16x16x32(a, b, c) \
+  __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(::cd::f16x8, a), __builtin_bit_cast(::cd::f16x8, b), c, 0, 0, 0)
 #else
 // ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------------------------
 __host__ __device__ inline float bf2f(bf16_t v) {
@@ -74,6 +76,7 @@ __device__ inline void unpack8(const uint4& raw, float* f) {
   f[6] = __uint_as_float(raw.w << 16); f[7] = __uint_as_float(raw.w & 0xffff0000u);
 }
 #define CD_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define CD_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #endif
 
 __device__ inline uint32_t pack2(float lo, float hi) {

@@ -176,7 +176,14 @@ class VAEKL : public VAE {
 
 VAEKL::VAEKL(const cd_net_desc& d) {
   desc = d;
-  CD_CHECK(d.precision == CD_PREC_16, "the autoencoders run in the 16-bit format only");
+  // round 5: the first stage in the reference's arithmetic too (`precision = "full"` covers the VAE,
+  // stable_diffusion_stochastic_text_wrapper.py:117, autoencoder.py:324-333): CD_PREC_F32 runs every layer on the fp32
+  // path (f32_path.hip), CD_PREC_F32X3 runs the GroupNorm-fed convolutions - 97 % of the FLOPs - as three-term split-fp16
+  // products and the rest (nin_shortcut, down / up-sampling convs on raw activations, the single-head attention) in fp32
+  f32 = d.precision == CD_PREC_F32 || d.precision == CD_PREC_F32X3;
+  x3 = d.precision == CD_PREC_F32X3;
+  params.f32 = f32; params.x3 = x3;
+  CD_CHECK(!(f32 && d.n_embed > 0), "the VQ first stage (codebook lookup on 16-bit rows) runs in the 16-bit format only");
   ch_ = d.model_channels; nres_ = d.num_res_blocks; nlev_ = d.n_mult;
   for (int i = 0; i < nlev_; ++i) mult_.push_back(d.channel_mult[i]);
   z_channels = d.z_channels; embed_ = d.embed_dim; in_ch_ = d.in_channels; out_ch_ = d.out_channels;
@@ -234,7 +241,10 @@ VAEKL::VAEKL(const cd_net_desc& d) {
 
 void VAEKL::encode_moments(Ctx& c, const bf16_t* img, int B, int R, float* moments) {
   const size_t mk = c.arena->mark();
-  Act x; x.p = (bf16_t*)img; x.B = B; x.H = R; x.W = R; x.C = round_up(in_ch_, 32); x.ld = x.C;
+  c.f32 = f32; c.x3 = x3;
+  const size_t esz = f32 ? 4 : 2;
+  Act x; x.p = (bf16_t*)img; x.B = B; x.H = R; x.W = R; x.C = round_up(in_ch_, 32); x.ld = x.C; x.f32 = f32;
+  if (x3) { x.split = true; x.ld = 2 * x.C; }  // the caller hands a split-mode network its input as fp16 pairs
   ConvOpts o3; o3.want_stats = true;
   Act h = conv_fwd(c, *e_in_, x, nullptr, o3);
   for (int l = 0; l < nlev_; ++l) {
@@ -248,20 +258,23 @@ void VAEKL::encode_moments(Ctx& c, const bf16_t* img, int B, int R, float* momen
   // conv_out -> bf16 padded to 32 channels so the 1x1 quant_conv can consume it
   const int cp = round_up(moments_, 32);
   Act mo = alloc_act(c, B, h.H, h.W, cp);
-  HIP_CHECK(hipMemsetAsync(mo.p, 0, (size_t)mo.rows() * cp * 2, c.st));
+  HIP_CHECK(hipMemsetAsync(mo.p, 0, (size_t)mo.rows() * cp * esz, c.st));
   ConvOpts oo; oo.out = mo.p; oo.out_ld = cp;
   conv_fwd(c, *e_out_, n, nullptr, oo);
   ConvOpts oq; oq.pad = 0; oq.out_f32 = true; oq.out = moments; oq.out_ld = moments_channels;
   conv_fwd(c, *quant_, mo, nullptr, oq);
   c.arena->release(mk);
+  c.f32 = false; c.x3 = false;
 }
 
 void VAEKL::decode(Ctx& c, const bf16_t* z, int B, int hl, float* img) {
   const size_t mk = c.arena->mark();
-  Act x; x.p = (bf16_t*)z; x.B = B; x.H = hl; x.W = hl; x.C = round_up(embed_, 32); x.ld = x.C;
+  c.f32 = f32; c.x3 = x3;
+  Act x; x.p = (bf16_t*)z; x.B = B; x.H = hl; x.W = hl; x.C = round_up(embed_, 32); x.ld = x.C; x.f32 = f32;
+  if (x3) { x.split = true; x.ld = 2 * x.C; }
   const int cp = round_up(z_channels, 32);
   Act zq = alloc_act(c, B, hl, hl, cp);
-  HIP_CHECK(hipMemsetAsync(zq.p, 0, (size_t)zq.rows() * cp * 2, c.st));
+  HIP_CHECK(hipMemsetAsync(zq.p, 0, (size_t)zq.rows() * cp * (f32 ? 4 : 2), c.st));
   ConvOpts oq; oq.pad = 0; oq.out = zq.p; oq.out_ld = cp;
   conv_fwd(c, *pq_, x, nullptr, oq);
   ConvOpts o3; o3.want_stats = true;
@@ -277,6 +290,7 @@ void VAEKL::decode(Ctx& c, const bf16_t* z, int B, int hl, float* img) {
   ConvOpts oo; oo.out_f32 = true; oo.out = img; oo.out_ld = out_ch_;
   conv_fwd(c, *d_out_, n, nullptr, oo);
   c.arena->release(mk);
+  c.f32 = false; c.x3 = false;
 }
 
 // ================================================================== Ho et al. DDPM U-Net

@@ -63,7 +63,9 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
                  n_trials=None, cond_stage=None, ranker=None, device=None, text_encoder=None,
                  noise_on_cpu=False, fold_ensemble=True, ranker_path=None, precision="fp16"):
         super().__init__()
-        # `[gan] precision`: arithmetic of the U-Net (the first stage and the text towers stay 16-bit). 'fp16' (default):
+        # `[gan] precision`: arithmetic of the U-Net AND (round 5) of the first stage - the reference's `precision = "full"` covers
+        # both (sd_wrapper:117, autoencoder.py:324-333); the text towers stay 16-bit (their output is the conditioning, rounded
+        # once). 'fp16' (default):
         # 16-bit storage, the benchmarked engine (55 dB against the reference on C2, 99-step self-cycle 2e-2 rms); 'fp32': the
         # reference's own arithmetic (`precision = "full"`, stable_diffusion_stochastic_text_wrapper.py:117) - fp32 storage,
         # fp32 matrix instructions, fp32 flash attention; 'fp32x3': the same network with every GroupNorm- / LayerNorm-fed
@@ -87,6 +89,7 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
         self.channels, self.image_size = udesc.in_channels, udesc.image_size
         self.unet = self.engine.create_net(udesc)
         vdesc = self.VAE_DESC()
+        vdesc.precision = TEXT_PRECISIONS[self.precision]
         self.vae = self.engine.create_net(vdesc)
         self.vae_factor = 2 ** (vdesc.n_mult - 1)
         ckpt = self.checkpoint_path(source_model_type)

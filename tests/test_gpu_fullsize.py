@@ -134,6 +134,37 @@ def test_kl_f8_vae_full_size_vs_oracle(engine, report, sd_vae):
     assert r2[0] < 1e-2 * FMT and r2[1] < 1e-2 * FMT, r2
 
 
+@pytest.mark.parametrize("prec", [_ffi.CD_PREC_F32, _ffi.CD_PREC_F32X3], ids=["fp32", "fp32x3"])
+def test_kl_f8_vae_full_size_fp32_modes_vs_oracle(engine, report, prec):
+    """The first stage in the reference's arithmetic (`precision = "full"` covers the VAE too,
+    stable_diffusion_stochastic_text_wrapper.py:117, autoencoder.py:324-333): AutoencoderKL encode (posterior mean) and decode
+    at 512 x 512 on the fp32 path, and in the split mode (GroupNorm-fed convolutions as three-term split-fp16 products, the
+    raw-input convs and the 4096-token single-head attention in fp32). 16-bit engine: 2.0e-3 / 5.9e-3 rel-to-max."""
+    if prec == _ffi.CD_PREC_F32X3 and FMT != 1.0:
+        pytest.skip("the split mode needs the fp16 build")
+    d = cda.kl_f8_vae_desc()
+    d.precision = prec
+    net = engine.create_net(d)
+    sd = nets.synth_state_dict(engine.net_params(net), 1)
+    n, first = engine.load_state_dict(net, sd)
+    assert n == 0, first
+    cfg = nets.VAECfg(ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2)
+    img = torch.rand((1, 3, 512, 512), generator=torch.Generator().manual_seed(4)) * 2 - 1
+    with torch.no_grad():
+        mom = nets.vae_encode_moments(sd, cfg, img)
+        zz = mom[:, :4] * 0.5
+        dec = nets.vae_decode(sd, cfg, zz)
+    z = engine.vae_encode(net, img.cuda(), sample=False, scale=1.0)
+    r1 = _rel(z, mom[:, :4])
+    dd = engine.vae_decode(net, zz.cuda(), scale=1.0)
+    engine.synchronize()  # the split mode's range guard reports here
+    r2 = _rel(dd, dec)
+    report.add("fullsize/kl_f8_vae_" + ("fp32" if prec == _ffi.CD_PREC_F32 else "fp32x3"), enc_rel_to_max=r1[0],
+               enc_mean_rel=r1[1], dec_rel_to_max=r2[0], dec_mean_rel=r2[1])
+    assert r1[0] < 1e-4 and r1[1] < 1e-4, r1
+    assert r2[0] < 1e-4 and r2[1] < 1e-4, r2
+
+
 @pytest.mark.parametrize("B", [17, 33])
 def test_kl_f8_vae_batches_beyond_2_gib_per_tensor(engine, report, sd_vae, B):
     """A 512 x 512 batch of 17 makes the decoder's 256-channel 512 x 512 activations (128 MiB per sample) larger than

@@ -389,6 +389,30 @@ def test_attention_ragged_tail_is_zero_filled(engine, report, vt):
     _check(report, "attention_ragged_tail/%s" % ("vt" if vt else "v"), got, ref, rel=4e-3 * f, mean=1.5e-3 * f)
 
 
+def test_attention_d40_long_ragged_keys_and_queries(engine, report):
+    """The long d = 40 self-attention kernel (k_attention_d40: K / V^T tiles by LDS-DMA, K rows gathered in permuted key
+    order, rows 32 .. 47 of O^T on the 16 x 16 x 32 matrix instruction) with a token count that is not a multiple of its
+    64-key tiles or 256-query workgroups: 1100 = 17 tiles + 12 keys, 4 workgroups + 76 queries. The ragged tile's mask
+    has to follow the key permutation, and rows beyond Tk must arrive as zeros: the second batch element's K / V are NaN
+    (they follow element 0's rows in memory)."""
+    g = torch.Generator().manual_seed(37)
+    B, H, D, T = 2, 2, 40, 1100
+    C = H * D
+    q = r16(torch.randn(B, T, C, generator=g))
+    k = r16(torch.randn(B, T, C, generator=g))
+    v = r16(torch.randn(B, T, C, generator=g))
+    k[1] = float("nan")
+    v[1] = float("nan")
+    scale = D ** -0.5
+    qh = q[:1].view(1, T, H, D).transpose(1, 2).double()
+    kh = k[:1].view(1, T, H, D).transpose(1, 2).double()
+    vh = v[:1].view(1, T, H, D).transpose(1, 2).double()
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1) @ vh).transpose(1, 2).reshape(1, T, C).float()
+    got = _ops.attention(engine, q, k, v, H, scale, v_transposed=True)[:1]
+    f = 1.0 if engine.lib.cd_act_format() == 1 else 8.0
+    _check(report, "attention_d40_long_ragged", got, ref, rel=4e-3 * f, mean=1.5e-3 * f)
+
+
 def test_softmax_rows(engine, report):
     g = torch.Generator().manual_seed(19)
     s = torch.randn(70, 1000, generator=g) * 4
