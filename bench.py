@@ -235,19 +235,23 @@ def cpu_baseline_reference():
 def pmc_traffic_per_launch():
     """HBM-side bytes per k_conv_gemm launch from the committed rocprofv3 PMC passes (profiles/README.md):
     FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over the U-Net forwards of one coalesced C2 launch set (B'=32
-    encode, B'=64 CFG decode), which launch equally often. None when the summaries are absent."""
+    encode, B'=64 CFG decode), which launch equally often. Returns (bytes, the files it read) - the figure is a
+    constant of the committed profile, not a measurement of this run, and the line says which files it came from;
+    (None, None) when the summaries are absent."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for rnd in ("r4", "r3", "r2b"):  # the newest committed pair
-        vals = []
+    for rnd in ("r5", "r4", "r3", "r2b"):  # the newest committed pair
+        vals, files = [], []
         for b in (32, 64):
+            name = "%s_conv_gemm_traffic_unet_b%d.json" % (rnd, b)
             try:
-                with open(os.path.join(prof, "%s_conv_gemm_traffic_unet_b%d.json" % (rnd, b))) as fh:
+                with open(os.path.join(prof, name)) as fh:
                     vals.append(float(json.load(fh)["bytes_per_launch"]))
+                files.append("profiles/" + name)
             except (OSError, KeyError, ValueError):
                 break
         if len(vals) == 2:
-            return sum(vals) / len(vals)
-    return None
+            return sum(vals) / len(vals), files
+    return None, None
 
 
 def _free_port():
@@ -264,9 +268,15 @@ def self_launch(n_ranks, argv):
     port, dmabuf IPC for RCCL - and hand back its exit code; rank 0's JSON line goes to this process's stdout."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n_ranks)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
-    return subprocess.call(cmd, env=env, cwd=ROOT)
+    rc = 1
+    for _attempt in range(3):  # the port is free when probed, not necessarily when torchrun binds it: try another one
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+        t0 = time.time()
+        rc = subprocess.call(cmd, env=env, cwd=ROOT)
+        if rc == 0 or time.time() - t0 > 60:  # a rendezvous that lost the race for its port fails within seconds
+            break
+    return rc
 
 
 def dry_main(a, wl, rank, world):
@@ -410,8 +420,8 @@ def main():
         a.precision = "fp32x3"
     if a.precision:
         # c5 / c5r: fp32x3 (default) | fp32 | fp16 (lossy). c2 / c3 / c2e: fp16 (default, the headline) | fp32x3 | fp32 = the
-        # text U-Net in the reference's arithmetic (`precision = "full"`; first stage and text towers stay 16-bit) - a labelled
-        # line beside the headline, never the headline
+        # text U-Net and (round 5) the first stage in the reference's arithmetic (`precision = "full"`) - a labelled line beside
+        # the headline, never the headline
         args.gan.precision = a.precision
         if a.workload in ("c5", "c5r") and a.precision not in ("fp32", "fp32x3"):
             args.gan.allow_lossy_ddim = True  # throughput-only line: the wrapper refuses 16-bit 'ddim' unless asked by name
@@ -564,7 +574,7 @@ def main():
         # split mode: algorithmic flops (2 M N K of the fp32 conv) against a third of the 16-bit MFMA peak
         peak = PEAK_F32_TFLOPS if f32 else (PEAK_TFLOPS / 3.0 if x3 else PEAK_TFLOPS)
         ach = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        traffic = pmc_traffic_per_launch() if a.workload == "c2" else None
+        traffic, traffic_source = pmc_traffic_per_launch() if a.workload == "c2" and not (f32 or x3) else (None, None)
         # the ceiling of THIS device on this lease, after the timed region: a bare 16-bit MFMA loop on every CU settles
         # where the package power cap lets it (MI355X, 1400 W: 1.7-1.8 GHz = 1.7-1.8 PFLOP/s)
         sustained = None
@@ -605,6 +615,7 @@ def main():
                           "peak = 16-bit MFMA peak / 3") if x3 else "k_conv_gemm (all tile instantiations)",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC, profiles/)",
+                         "traffic_source": traffic_source,
                          "operating_point": ("the ensemble's engine calls at their real batch sizes on 4-step chains (skip 95), "
                                              "per-launch HIP events") if ensemble else
                          "one launch set of %d steps, single stream, per-launch HIP events" % C,

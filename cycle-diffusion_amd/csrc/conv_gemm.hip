@@ -530,8 +530,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
     // 8-row pass on exposed LDS / L2 latency, and the statistics another 0.45 k on a 48-shuffle butterfly plus sixteen
     // 8-lane stores). GroupNorm statistics of the block: per-lane partial sums over the block's passes, transposed through
     // the LDS rows just consumed, column sums by the lane that owns the column -> two dense 256-byte stores.
+    // (16-byte vector accesses below: row strides AND base pointers must be multiples of 16 bytes - the batch strides are
+    // element counts that keep the alignment when the leading dimensions do; odd shapes take the generic loop)
     const bool fast = !geglu && !p.out_f32 && !p.resid_f32 && p.act == ACT_NONE && (p.N & 7) == 0 && (p.out_ld & 7) == 0 &&
-                      (!p.resid || (p.resid_ld & 7) == 0) && (!p.rowvec || p.rows_per_vec >= p.M || (p.rows_per_vec & 31) == 0);
+                      (((uintptr_t)p.out | (uintptr_t)p.resid | (uintptr_t)p.rowvec) & 15) == 0 && (p.o_bs & 7) == 0 &&
+                      (!p.resid || (p.resid_ld & 7) == 0) &&
+                      (!p.rowvec || ((p.rowvec_ld & 3) == 0 && (p.rows_per_vec >= p.M || (p.rows_per_vec & 31) == 0)));
     if (fast) {
       constexpr int LD = T::EPI_LD;
       const int RPP = 64 / (cw / 8), NP = 32 / RPP;  // rows per pass, passes per 32-row block (compile-time: cw is)
@@ -1028,6 +1032,21 @@ void tune_cache_append(const ShapeKey& k, int val) {
 
 std::mutex g_tune_mu;  // engines on different host threads share one table; tuning itself is serialised
 
+// CU count of the current device (256 on an unpartitioned MI355X; a partitioned part has fewer): "does this configuration
+// fill the chip" is asked against it, not against a literal
+int device_cu_count() {
+  static std::atomic<int> ncu_of[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int n = ncu_of[dev & 63].load(std::memory_order_relaxed);
+  if (!n) {
+    hipDeviceProp_t prop;
+    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    ncu_of[dev & 63].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 int tuned_config(hipStream_t st, const ConvGemmParams& p, bool k64) {
   std::lock_guard<std::mutex> lock(g_tune_mu);
   ConvTuner& tu = g_conv_tuner;
@@ -1073,7 +1092,7 @@ int tuned_config(hipStream_t st, const ConvGemmParams& p, bool k64) {
     if (split > 1) {
       // a split only where THIS tile configuration leaves CUs idle (round 4: the wide tiles on the 16 x 16 level have 128
       // tiles at B' = 32; their K loop is the fastest, two K ranges each fill the chip)
-      if (!sk.scratch || tiles >= 256 || nk < 4 * split || tiles * split > 2048) continue;
+      if (!sk.scratch || tiles >= device_cu_count() || nk < 4 * split || tiles * split > 2048) continue;
       if ((size_t)tiles * split * c.BM * c.BN * 4 > sk.scratch_bytes || tiles > sk.nflags) continue;
     }
     q.splitk = split; q.sk_scratch = sk.scratch; q.sk_flags = sk.flags;

@@ -456,15 +456,25 @@ Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x_in, bool dup) {
       conv_fwd(c, *s.o2, a, nullptr, o);
       c.arena->release(m2);
     }
-    {  // GEGLU feed-forward: projection materialised, exact-erf GELU in fp32
-      const size_t m2 = c.arena->mark();
-      Act n3 = layernorm_fwd(c, s.ln3, h);
-      ConvOpts pg; pg.pad = 0; pg.raw_geglu = true;
-      Act g8 = conv_fwd(c, *s.ff1, n3, nullptr, pg);  // [B*T][8C] in packed [32 value | 32 gate] blocks
-      Act g = geglu_f32_fwd(c, g8);                   // [B*T][4C]
-      ConvOpts o; o.pad = 0; o.resid = &h; o.out = h.p; o.out_ld = h.ld;
-      conv_fwd(c, *s.ff2, g, nullptr, o);
-      c.arena->release(m2);
+    {  // GEGLU feed-forward: projection materialised, exact-erf GELU in fp32 - in row chunks, so that the [rows][8C] fp32
+       // projection stays below 1 GiB whatever the fold (at 64 x 64 and C = 320 a B' = 64 batch would need 2.7 GB for it on top
+       // of the attention buffers; every row is independent, so chunking changes no value)
+      const int64_t rows = h.rows();
+      int64_t chunk = ((int64_t)1 << 30) / ((int64_t)8 * C * 4);
+      chunk = std::max<int64_t>(4096, chunk & ~(int64_t)4095);
+      for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
+        const int64_t n = std::min(chunk, rows - r0);
+        const size_t m2 = c.arena->mark();
+        Act hv = h;  // rows [r0, r0 + n) of the token stream as an [1][n][1][C] activation
+        hv.p = (bf16_t*)(h.pf() + r0 * h.ld); hv.B = 1; hv.H = (int)n; hv.W = 1;
+        Act n3 = layernorm_fwd(c, s.ln3, hv);
+        ConvOpts pg; pg.pad = 0; pg.raw_geglu = true;
+        Act g8 = conv_fwd(c, *s.ff1, n3, nullptr, pg);  // [n][8C] in packed [32 value | 32 gate] blocks
+        Act g = geglu_f32_fwd(c, g8);                   // [n][4C]
+        ConvOpts o; o.pad = 0; o.resid = &hv; o.out = hv.p; o.out_ld = hv.ld;
+        conv_fwd(c, *s.ff2, g, nullptr, o);
+        c.arena->release(m2);
+      }
     }
     ConvOpts po; po.pad = 0; po.resid = &x; po.out = out.p; po.out_ld = out.ld; po.out_stats = out.stats_buf;
     if (c.x3) {  // the residual stream as fp16 pairs: proj_out is a split product too, and its epilogue emits the statistics

@@ -73,6 +73,8 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
         if str(precision) not in TEXT_PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(TEXT_PRECISIONS))
         self.precision = str(precision)
+        if self.precision == "fp32x3" and _ffi.load_library().cd_act_format() != 1:
+            raise ValueError("precision='fp32x3' needs the fp16 build of the library (this is the bf16 build): use 'fp32'")
         self.encoder_unconditional_guidance_scales = encoder_unconditional_guidance_scales
         self.decoder_unconditional_guidance_scales = decoder_unconditional_guidance_scales
         self.n_trials = n_trials

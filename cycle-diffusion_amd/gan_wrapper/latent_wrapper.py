@@ -38,7 +38,7 @@ class LatentDiffStochasticWrapper(torch.nn.Module):
 
     def __init__(self, source_model_type, custom_steps, eta, white_box_steps, refine_steps=0,
                  enforce_class_input=None, unconditional_guidance_scale=None, device=None, noise_on_cpu=False,
-                 unet_desc=None, vae_desc=None, state_dict=None, precision="fp32x3", allow_lossy_16bit=False):
+                 unet_desc=None, vae_desc=None, state_dict=None, precision=None, allow_lossy_16bit=False):
         super().__init__()
         if enforce_class_input:
             raise NotImplementedError("class-conditional LDMs (cin256) are not used by the reference configs")
@@ -57,6 +57,11 @@ class LatentDiffStochasticWrapper(torch.nn.Module):
         # round-off of eps_hat (full-size fixture, 99 steps: 25 dB against the reference's latent; 'fp32' 73 dB, 'fp32x3'
         # 76 dB - tests/test_gpu_ldm_uncond.py). The 16-bit engine is therefore refused unless asked for by name AND
         # acknowledged (`allow_lossy_16bit`), as DDPMDDIMWrapper refuses 16-bit 'ddim' chains (allow_lossy_ddim).
+        fp16_build = _ffi.load_library().cd_act_format() == 1  # a property of the library: no engine (no GPU) needed yet
+        if precision is None:
+            # the split mode packs its weights as fp16 pairs: it exists in the fp16 build only (launch_pack_w3); the bf16
+            # build (CD_ACT_FP16=0) falls back to the plain fp32 path, which holds the same parity at a third of the speed
+            precision = "fp32x3" if fp16_build else "fp32"
         if str(precision) not in LDM_PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(LDM_PRECISIONS))
         self.precision = str(precision)
@@ -65,7 +70,10 @@ class LatentDiffStochasticWrapper(torch.nn.Module):
             udesc.precision = LDM_PRECISIONS[self.precision]
         else:  # an explicit descriptor carries its own precision
             self.precision = {v: k for k, v in LDM_PRECISIONS.items() if k != "16"}[int(udesc.precision)]
-        if unet_desc is None and LDM_PRECISIONS[self.precision] == _ffi.CD_PREC_16 and not allow_lossy_16bit:
+        if LDM_PRECISIONS[self.precision] == _ffi.CD_PREC_F32X3 and not fp16_build:
+            raise ValueError("precision='fp32x3' needs the fp16 build of the library (this is the bf16 build): use 'fp32'")
+        # the refusal covers an explicit descriptor too: a CD_PREC_16 `unet_desc` is the same lossy engine
+        if LDM_PRECISIONS[self.precision] == _ffi.CD_PREC_16 and not allow_lossy_16bit:
             raise ValueError("precision=%r does not reproduce the reference on the eta-0.1 chains of the unconditional LDMs "
                              "(about 25 dB latent signal-to-error after 99 steps against 73-76 dB); use 'fp32x3' (default) "
                              "or 'fp32', or pass allow_lossy_16bit=True" % self.precision)

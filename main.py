@@ -7,6 +7,14 @@ L2 against the input; CLIP / directional CLIP when the config selects `ranker = 
 
   python main.py --cfg experiments/toy_ddpm_c1.cfg --data triplets.json --output_dir out [--per_device_eval_batch_size 4]
   python -m torch.distributed.run --nproc-per-node 8 main.py ...        # one process per GPU
+
+`--fold N` is the engine's look-ahead: N consecutive dataloader batches of this rank run as ONE model() call (the operating
+point bench.py's headline is measured at: 8 batches of 4 = 32 images through the DPM-Encoder, 64 rows through the guided
+decode), and the outputs are split back per sample. The reference's driver issues one batch per call
+(trainer/trainer.py:788-833 with --per_device_eval_batch_size 4, README.md:153); the samples of a batch are independent, so
+folding changes no result beyond kernel summation order. To make that checkable, every dataloader batch owns its noise
+stream (a device generator seeded by --seed and the batch's first sample id): a run's images do not depend on --fold, on the
+number of ranks, or on which rank a batch lands.
 """
 import argparse
 import json
@@ -28,6 +36,10 @@ def main(argv=None):
     ap.add_argument("--per_device_eval_batch_size", type=int, default=4)
     ap.add_argument("--range", type=int, nargs=2, default=None, metavar=("START", "END"))
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--fold", type=int, default=1,
+                    help="look-ahead: run N consecutive batches of this rank as one model() call (larger GEMMs; bench.py's "
+                         "headline operating point is --per_device_eval_batch_size 4 --fold 8); results per image are those of "
+                         "--fold 1 up to kernel summation order")
     ap.add_argument("--grid", action="store_true",
                     help="also write the reference's multi_image pair grids (original | translated, 8 per row)")
     ap.add_argument("--synthetic-weights", action="store_true",
@@ -62,8 +74,36 @@ def main(argv=None):
     rows, grid_pairs = [], []
     import time
     t_start, n_done = time.perf_counter(), 0
-    for step_idx in shard_indices(len(ds), a.per_device_eval_batch_size, world, rank):
-        batch = collate([ds[i] for i in step_idx])
+    steps = shard_indices(len(ds), a.per_device_eval_batch_size, world, rank)
+    wrappers = [w for w in (getattr(model, "gan_wrapper", None), getattr(model, "source_gan_wrapper", None),
+                            getattr(model, "target_gan_wrapper", None)) if w is not None]
+
+    class BatchStreams:
+        """noise_source of the wrappers: one device generator per dataloader batch of the folded call; a draw of shape
+        [sum of batch sizes, ...] is the concatenation of each batch's own draw (what a --fold 1 run draws for it)"""
+
+        def __init__(self, first_ids, sizes):
+            self.sizes = sizes
+            self.gens = [torch.Generator(device=dev).manual_seed((a.seed * 1000003 + 7919 * int(i)) % (2 ** 63)) for i in first_ids]
+
+        def __call__(self, shape):
+            assert shape[0] == sum(self.sizes), (shape, self.sizes)
+            return torch.cat([torch.randn((n,) + tuple(shape[1:]), generator=g, device=dev)
+                              for n, g in zip(self.sizes, self.gens)], 0)
+
+    fold = max(1, a.fold)
+    for c0 in range(0, len(steps), fold):
+        chunk = steps[c0:c0 + fold]
+        parts = [collate([ds[i] for i in step_idx]) for step_idx in chunk]
+        batch = {"sample_id": torch.cat([p["sample_id"] for p in parts]),
+                 "original_image": torch.cat([p["original_image"] for p in parts])}
+        for k in ("encode_text", "decode_text"):
+            if k in parts[0]:
+                batch[k] = [t for p in parts for t in p[k]]
+        streams = BatchStreams([int(p["sample_id"][0]) for p in parts], [int(p["sample_id"].shape[0]) for p in parts])
+        for w in wrappers:
+            if hasattr(w, "noise_source"):
+                w.noise_source = streams
         kw = {"sample_id": batch["sample_id"].to(dev), "original_image": batch["original_image"].to(dev)}
         if "encode_text" in batch:
             kw.update(encode_text=batch["encode_text"], decode_text=batch["decode_text"])

@@ -36,7 +36,8 @@ def _wrapper(fx, refine_steps, precision=_ffi.CD_PREC_16):
         warnings.simplefilter("ignore")
         w = LatentDiffStochasticWrapper("celeba256", custom_steps=int(fx["steps"]), eta=0.1,
                                         white_box_steps=int(fx["steps"]) + 1, refine_steps=refine_steps, noise_on_cpu=True,
-                                        unet_desc=tiny_uncond_unet_desc(precision), vae_desc=tiny_vq_desc())
+                                        unet_desc=tiny_uncond_unet_desc(precision), vae_desc=tiny_vq_desc(),
+                                        allow_lossy_16bit=True)
     usd = nets.synth_state_dict(json.loads(str(fx["unet_names"])), int(fx["useed"]))
     vsd = nets.synth_state_dict(json.loads(str(fx["vae_names"])), int(fx["vseed"]))
     for net, sd in ((w.unet, usd), (w.vae, vsd)):
@@ -222,7 +223,7 @@ def test_ema_shadow_weights_are_what_the_unet_runs_on():
         ckpt["model_ema." + ("diffusion_model." + k).replace(".", "")] = v
     ckpt["model_ema.decay"], ckpt["model_ema.num_updates"] = torch.tensor(0.9999), torch.tensor(1)
     kw = dict(custom_steps=int(fx["steps"]), eta=0.1, white_box_steps=int(fx["steps"]) + 1, noise_on_cpu=True,
-              unet_desc=tiny_uncond_unet_desc(), vae_desc=tiny_vq_desc())
+              unet_desc=tiny_uncond_unet_desc(), vae_desc=tiny_vq_desc(), allow_lossy_16bit=True)
     w_ema = LatentDiffStochasticWrapper("celeba256", state_dict=ckpt, **kw)
     w_ref, _ = _wrapper(fx, 0)
     x = gu.rnd((1, 3, 16, 16), 5).cuda()

@@ -8,6 +8,7 @@ import warnings
 import pytest
 import torch
 
+from cycle_diffusion_amd import _ffi
 from cycle_diffusion_amd.utils.config_utils import get_config
 from cycle_diffusion_amd.utils.program_utils import get_model
 
@@ -57,6 +58,48 @@ def test_main_driver_on_the_c1_config(tmp_path):
     assert len(res["samples"]) == 3 and [r["sample_id"] for r in res["samples"]] == [0, 1, 2]
     assert all(np.isfinite(r["psnr"]) and 0 <= r["ssim"] <= 1 for r in res["samples"])
     assert sorted(p.name for p in out.glob("*.png")) == ["000000.png", "000001.png", "000002.png"]
+
+
+def test_main_driver_fold_look_ahead_matches_batch_by_batch_on_c2(tmp_path):
+    """`main.py --fold N` (N dataloader batches in one model() call - the operating point of bench.py's headline) against the
+    reference's batch-by-batch loop (trainer/trainer.py:788-833, README.md:153 `--per_device_eval_batch_size 4`) on the C2
+    configuration at its real size (SD-v1.4-shaped U-Net + KL-f8 VAE, 512 x 512, 99 + 99 steps, CFG 3; synthetic weights):
+    6 triplets as 3 batches of 2, once with --fold 1 and once with --fold 3 (one call of 6 images: other tiles, split-K
+    factors, streaming kernels). Every image of the folded run must match its batch-by-batch twin >= 45 dB (the PNGs
+    themselves, 8-bit), be a different image from its neighbours, and carry the same sample ids / texts in metrics.json."""
+    import json
+    import sys
+    import numpy as np
+    from PIL import Image
+    rng = np.random.RandomState(3)
+    meta = []
+    for i in range(6):
+        Image.fromarray(rng.randint(0, 255, (64, 64, 3), dtype=np.uint8)).resize((512, 512), Image.BICUBIC).save(
+            tmp_path / ("im%d.png" % i))
+        meta.append({"img_path": "im%d.png" % i, "encode_text": "source %d" % i, "decode_text": "target %d" % i})
+    (tmp_path / "data.json").write_text(json.dumps(meta))
+    sys.path.insert(0, ROOT)
+    import main as driver
+    outs = {}
+    for fold in (1, 3):
+        out = tmp_path / ("out_fold%d" % fold)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert driver.main(["--cfg", "experiments/bench_sd_c2.cfg", "--data", str(tmp_path / "data.json"),
+                                "--output_dir", str(out), "--per_device_eval_batch_size", "2", "--fold", str(fold),
+                                "--synthetic-weights"]) == 0
+        res = json.loads((out / "metrics.json").read_text())
+        assert [r["sample_id"] for r in res["samples"]] == list(range(6))
+        assert [r["decode_text"] for r in res["samples"]] == ["target %d" % i for i in range(6)]
+        outs[fold] = [np.asarray(Image.open(out / ("%06d.png" % i)), dtype=np.float64) / 255.0 for i in range(6)]
+    ps = []
+    for a_, b_ in zip(outs[1], outs[3]):
+        mse = float(((a_ - b_) ** 2).mean())
+        ps.append(99.0 if mse == 0 else -10.0 * np.log10(mse))
+    spread = min(float(np.abs(outs[3][i] - outs[3][i + 1]).mean()) for i in range(5))
+    fmt = 1.0 if _ffi.load_library().cd_act_format() == 1 else 8.0
+    assert min(ps) >= (45.0 if fmt == 1.0 else 25.0), ps
+    assert spread > 1e-3, spread
 
 
 def test_unconditional_ldm_translation_config_at_full_size(tmp_path):

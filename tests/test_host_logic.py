@@ -204,7 +204,14 @@ def test_unconditional_ldm_wrapper_refuses_the_lossy_16bit_engine_by_default():
     engine is created (no GPU needed)."""
     import inspect
     from cycle_diffusion_amd.gan_wrapper.latent_wrapper import LatentDiffStochasticWrapper
-    assert inspect.signature(LatentDiffStochasticWrapper.__init__).parameters["precision"].default == "fp32x3"
+    # default None = 'fp32x3' on the fp16 build of the library, 'fp32' on the bf16 build (which has no split mode)
+    assert inspect.signature(LatentDiffStochasticWrapper.__init__).parameters["precision"].default is None
+    from cycle_diffusion_amd import _ffi
+    from cycle_diffusion_amd.engine import ldm_uncond_unet_desc
+    d16 = ldm_uncond_unet_desc()
+    d16.precision = _ffi.CD_PREC_16
+    with pytest.raises(ValueError, match="allow_lossy_16bit"):  # an explicit 16-bit descriptor is the same lossy engine
+        LatentDiffStochasticWrapper("celeba256", custom_steps=99, eta=0.1, white_box_steps=100, unet_desc=d16)
     with pytest.raises(ValueError, match="allow_lossy_16bit"):
         LatentDiffStochasticWrapper("celeba256", custom_steps=99, eta=0.1, white_box_steps=100, precision="fp16")
     with pytest.raises(ValueError, match="precision must be one of"):
