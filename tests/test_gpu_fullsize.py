@@ -91,6 +91,31 @@ def test_sd_unet_forward_full_size_fp32_modes_vs_oracle(engine, report, prec):
     assert rmax < 1e-4 and rmean < 1e-4, (rmax, rmean)
 
 
+def test_sd_unet_fp32_modes_feed_forward_row_chunks_at_batch_26(engine, report):
+    """On the fp32 path the GEGLU projection is materialised ([rows][8C] fp32) and therefore runs in row chunks of at most
+    1 GiB (unet_openai.hip st_fwd): at 64 x 64 and C = 320 that is 102 400 rows = 25 images, so a batch of 26 puts its last
+    image into a second chunk. Every sample of the batch must equal its own one-sample forward to fp32 summation order."""
+    if FMT != 1.0:
+        pytest.skip("the split mode needs the fp16 build")
+    d = cda.sd_v1_unet_desc()
+    d.precision = _ffi.CD_PREC_F32X3
+    net = engine.create_net(d)
+    sd = nets.synth_state_dict(engine.net_params(net), 0)
+    assert engine.load_state_dict(net, sd)[0] == 0
+    del sd
+    B = 26
+    x, c, _ = _inputs(B, seed=9)
+    t = torch.full((B,), 500.0)
+    y = engine.unet_forward(net, x.cuda(), t.cuda(), c.cuda())
+    engine.synchronize()
+    worst = 0.0
+    for i in (0, 24, 25):
+        y1 = engine.unet_forward(net, x[i:i + 1].cuda(), t[i:i + 1].cuda(), c[i:i + 1].cuda())
+        worst = max(worst, _rel(y[i:i + 1], y1)[0])
+    report.add("fullsize/sd_unet_fp32x3_batch26_vs_alone", rel_to_max=worst)
+    assert torch.isfinite(y).all() and worst < 1e-4, worst
+
+
 def test_sd_unet_forward_batch16_streaming_linears_vs_oracle(engine, report, sd_unet):
     """The same U-Net at batch 16: the 64 x 64 level then has 65536 token rows, where the 320-channel linears run on
     the streaming kernel (csrc/lin_stream.hip) and norm2 / norm3 are folded into the cross-attention query and GEGLU
