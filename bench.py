@@ -16,11 +16,14 @@ forward = wrapper.encode (VAE encode + DPM-Encoder) + wrapper.forward (coupled d
 i.e. exactly what Trainer.prediction_step times in the reference (trainer/trainer.py:788-789), followed
 by the per-step output gather (trainer.py:833). Prints ONE JSON line on rank 0.
 
-Steps are issued `--coalesce` at a time (default: 8 for C2, 4 otherwise): the engine folds the queued batches into
-ONE launch set (C2: 32 images through the DPM-Encoder, 64 rows through the CFG decode), so every GEMM sees 8x the
-rows with one copy of the weights; each step still gets its own all-gather, in step order. `--coalesce 4` / `1` are
-the round-2a / round-1 operating points (measured beside the default, profiles/). `--in-flight R` additionally
-keeps R such launch sets running on R independent engines / HIP streams.
+Steps are issued `--coalesce` at a time (default: 16 for C2, 4 otherwise): the engine folds the queued batches into
+ONE launch set (C2: 64 images through the DPM-Encoder, 128 rows through the CFG decode, the first stage in calls of 32
+images), so every GEMM sees 16x the rows with one copy of the weights; each step still gets its own all-gather, in step
+order. `--coalesce 8` / `4` / `1` are the rounds-2b..4 / round-2a / round-1 operating points (8 against 16 on one box:
+3.35 -> 3.44 images/s, profiles/r5_bench_lines_coalesce_8_vs_16.json; every one of them is pinned to the reference by
+tests/test_gpu_e2e_fullsize.py's folded-batch tests). The line also carries `single_batch` - launch sets of ONE step, the
+operating point of the reference's own driver loop. `main.py --fold N` is the same look-ahead for real data. `--in-flight R`
+additionally keeps R such launch sets running on R independent engines / HIP streams.
 
 Other BASELINE.json configurations: `--workload c3` (LDM text2img-large shapes, 256 x 256, batch 16) and
 `--workload c5r` (AFHQ improved-DDPM pair, 256 x 256, batch 4; REDUCED chain custom_steps 100 / es_steps 85 /
@@ -51,7 +54,7 @@ PEAK_TFLOPS = 2500.0  # dense 16-bit MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3  # fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
 
 WORKLOADS = {
-    "c2": dict(cfg="experiments/bench_sd_c2.cfg", res=512, batch=4, text=True, flop_per_image=F_IMG, coalesce=8,
+    "c2": dict(cfg="experiments/bench_sd_c2.cfg", res=512, batch=4, text=True, flop_per_image=F_IMG, coalesce=16,
                metric="images/sec, SD-v1.4 512px CycleDiffusion 100+100 steps, 1/2/4/8 MI355X",
                name="C2: Stable-Diffusion-v1.4-shaped U-Net + KL-f8 VAE, 512x512, custom_steps=99 "
                     "white_box_steps=100 eta=0.1 skip 0, 1 trial, encoder scale 1, decoder CFG 3"),
@@ -362,7 +365,7 @@ def main():
     ap.add_argument("--coalesce", type=int, default=0,
                     help="steps folded into one engine launch set (same images in flight as that many replicas, ONE "
                          "copy of the weights, that many times the rows per GEMM); 1 = one launch set per step; "
-                         "0 = the workload's default (8 for c2, 4 otherwise)")
+                         "0 = the workload's default (16 for c2 - round 5; rounds 2-4: 8 - and 4 otherwise)")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="launch sets in flight per GPU: independent engine replicas (own HIP stream, workspace and "
                          "weights) driven by host threads")
@@ -432,7 +435,7 @@ def main():
         args.gan.fold_ensemble = not a.no_fold
         args.gan.text_encoder = "clip"  # FrozenCLIPEmbedder on the engine (synthetic weights; hashing tokenizer)
     # Engine replicas: replica r owns stream r, its own engine (workspace, split-K scratch) and weights. With the
-    # default coalescing one replica already keeps 32 images in flight (C2); more replicas only overlap kernel tails.
+    # default coalescing one replica already keeps 64 images in flight (C2); more replicas only overlap kernel tails.
     n_rep = max(1, a.in_flight)
     C = a.coalesce if a.coalesce > 0 else wl.get("coalesce", 4)
     os.environ["CYCLEDIFF_SHARE_SYNTH"] = "1" if n_rep > 1 else "0"  # generate the synthetic weights once per rank

@@ -57,6 +57,10 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
     SCALE_FACTOR = 0.18215
     VAE_DESC = staticmethod(kl_f8_vae_desc)
     MAX_FOLD = 32  # samples per engine call when ensemble members are folded into the batch
+    # first-stage calls are cut at this many pixels (32 images of 512 x 512): the KL-f8 decoder's 512 x 512 x 128-channel
+    # level is 64 MiB per image and tensor in 16 bits (256 MiB in fp32), several of them live at once - a look-ahead fold of
+    # 64 images through ONE decode would need ~25 GB of workspace for 1.5 % of the path's FLOPs
+    VAE_MAX_PIXELS = 32 * 512 * 512
 
     def __init__(self, source_model_type, custom_steps, eta, white_box_steps, skip_steps,
                  encoder_unconditional_guidance_scales=None, decoder_unconditional_guidance_scales=None,
@@ -150,6 +154,11 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
     def _schedule(self):
         return schedule.DDIMSchedule(self.alphas_cumprod, self.custom_steps, self.eta)
 
+    def _vae_batch(self):
+        """images per first-stage call (fp32 / split-mode activations are twice the bytes of the 16-bit ones)"""
+        px = self.VAE_MAX_PIXELS if self.precision == "fp16" else self.VAE_MAX_PIXELS // 2
+        return max(1, px // (self.resolution * self.resolution))
+
     def _randn(self, shape, cpu=None):
         """One noise draw. `noise_source` (a callable shape -> CPU tensor; parity tests) replaces the generator: it lets
         a test hand every sample of a batch its own stream, e.g. the stream a fixture was made with."""
@@ -190,8 +199,10 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
             # DiagonalGaussianDistribution.sample draws on the CPU and moves (distributions.py:36)
             h = self.resolution // self.vae_factor
             noise = self._randn((bsz, self.channels, h, h), cpu=True)
-        x0 = self.engine.vae_encode(self.vae, image, noise=noise, sample=self.SAMPLE_POSTERIOR,
-                                    scale=self.SCALE_FACTOR)
+        per = self._vae_batch()
+        x0 = torch.cat([self.engine.vae_encode(self.vae, image[i:i + per], noise=None if noise is None else noise[i:i + per],
+                                               sample=self.SAMPLE_POSTERIOR, scale=self.SCALE_FACTOR)
+                        for i in range(0, bsz, per)], 0)
         sch = self._schedule()
         assert self.eta > 0
         c, uc = self.get_condition(encode_text, bsz)
@@ -283,7 +294,9 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
                                             noise_tail=None if jobs[idx[0]][4] is None else
                                             torch.cat([jobs[i][4] for i in idx], dim=1).contiguous())
                 # decode_first_stage, then post_process (x+1)/2 fused into the final layout kernel
-                img = self.engine.vae_decode(self.vae, x, scale=self.SCALE_FACTOR, out_mul=0.5, out_add=0.5)
+                per = self._vae_batch()
+                img = torch.cat([self.engine.vae_decode(self.vae, x[i:i + per].contiguous(), scale=self.SCALE_FACTOR,
+                                                        out_mul=0.5, out_add=0.5) for i in range(0, x.shape[0], per)], 0)
                 for j, i in enumerate(idx):
                     img_ensemble[jobs[i][0]] = img[j * bsz:(j + 1) * bsz]
         return img_ensemble

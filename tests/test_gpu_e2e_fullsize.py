@@ -301,8 +301,8 @@ def _folded(report, cls, model_type, fx_name, res, ctx_dim, B, slot, tag):
     streams. EVERY slot of the batch is checked (round 4: samples 16+ of a folded first-stage decode read zeros for two
     rounds while a one-slot check stayed green):
       * the fixture's slot against the REFERENCE's image (the B = 1 floor) and against its own B = 1 result;
-      * slots 0, 15, 16, B - 1 (either side of the 2 GiB boundary of the first-stage decoder, and the ends) against THEIR
-        B = 1 runs: >= 45 dB each (tile choices never change a bit; split-K factors and the streaming / tile kernel choice
+      * slots 0, 15, 16, 32, B - 1 (either side of the 2 GiB boundary of the first-stage decoder, the first image of a second
+        first-stage call, and the ends) against THEIR B = 1 runs: >= 45 dB each (tile choices never change a bit; split-K factors and the streaming / tile kernel choice
         change fp32 summation order, which the 198-step chain amplifies);
       * every slot's image against the first-stage decode of ITS OWN target latent at batch 1 (the latents the wrapper
         handed to vae_decode are recorded): >= 50 dB - a slot decoded from zeros, from a neighbour's latent or from a
@@ -349,14 +349,15 @@ def _folded(report, cls, model_type, fx_name, res, ctx_dim, B, slot, tag):
                 out = w(z, x, [src[b] for b in sel], [tgt[b] for b in sel]).cpu()
         finally:
             w.engine.vae_decode = real_decode
-        assert len(latents) == 1 and latents[0].shape[0] == len(sel)  # ONE first-stage call for the whole batch
-        return out, z[0].cpu(), latents[0]
+        # the wrapper cuts first-stage calls at 32 x 512 x 512 pixels (two calls for 64 images of 512 x 512)
+        assert sum(x.shape[0] for x in latents) == len(sel) and all(x.shape[0] <= w._vae_batch() for x in latents)
+        return out, z[0].cpu(), torch.cat(latents, 0)
 
     imgB, zB, latB = run(list(range(B)))
     assert imgB.shape[0] == B and torch.isfinite(imgB).all()
     ref = torch.as_tensor(fx["img"])
     # ---- spread slots (and the fixture's) against their own B = 1 runs
-    spread = sorted({0, 15, 16, B - 1, slot} & set(range(B)))
+    spread = sorted({0, 15, 16, 32, B - 1, slot} & set(range(B)))
     p_alone, z_alone = {}, {}
     for b in spread:
         img1, z1, _ = run([b])
@@ -399,6 +400,13 @@ def test_c2_fixture_triplet_folded_into_a_batch_of_32(report):
     streaming kernel). Here the fixture's triplet is sample 21 of a 32-batch (beyond the first 16: the 2 GiB boundary of the VAE decoder, test_kl_f8_vae_batches_beyond_2_gib_per_tensor) (stable_diffusion_stochastic_text_wrapper.py:
     169-249 on a batch)."""
     _folded(report, SDStochasticTextWrapper, "sd-v1-4.ckpt", "c2_sd512_e2e", 512, 768, 32, 21, "c2_folded_b32")
+
+
+def test_c2_fixture_triplet_folded_into_a_batch_of_64(report):
+    """Round 5: bench.py's default C2 launch set folds 16 steps of 4 triplets - B' = 64 through the DPM-Encoder, 128 rows
+    through the guided decode, two first-stage calls of 32 images. The fixture's triplet is sample 53 of such a batch (in the
+    second first-stage call, beyond the 2 GiB boundary inside it): same floors, every slot checked."""
+    _folded(report, SDStochasticTextWrapper, "sd-v1-4.ckpt", "c2_sd512_e2e", 512, 768, 64, 53, "c2_folded_b64")
 
 
 def test_c3_fixture_triplet_folded_into_a_batch_of_64(report):
