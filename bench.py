@@ -16,7 +16,8 @@ forward = wrapper.encode (VAE encode + DPM-Encoder) + wrapper.forward (coupled d
 i.e. exactly what Trainer.prediction_step times in the reference (trainer/trainer.py:788-789), followed
 by the per-step output gather (trainer.py:833). Prints ONE JSON line on rank 0.
 
-Steps are issued `--coalesce` at a time (default: 16 for C2, 4 otherwise): the engine folds the queued batches into
+Steps are issued at most `--coalesce` at a time (default: 16 for C2, 4 otherwise) in launch sets of equal size (20 steps =
+10 + 10, `config.launch_sets`): the engine folds the queued batches into
 ONE launch set (C2: 64 images through the DPM-Encoder, 128 rows through the CFG decode, the first stage in calls of 32
 images), so every GEMM sees 16x the rows with one copy of the weights; each step still gets its own all-gather, in step
 order. `--coalesce 8` / `4` / `1` are the rounds-2b..4 / round-2a / round-1 operating points (8 against 16 on one box:
@@ -257,6 +258,16 @@ def pmc_traffic_per_launch():
     return None, None
 
 
+def launch_sets(steps, cap):
+    """K queued steps as launch sets of at most `cap` steps, as evenly as possible - 20 steps at cap 16 are 10 + 10, not
+    16 + 4: no small tail set (the policy the wrappers apply to ensemble members, latent_text_wrapper._chunks)"""
+    if steps <= 0:
+        return []
+    n_sets = -(-steps // cap)
+    size = -(-steps // n_sets)
+    return [size] * (n_sets - 1) + [steps - size * (n_sets - 1)]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -296,7 +307,7 @@ def dry_main(a, wl, rank, world):
     lo, hi = shard_range(B * world, world, rank)
     g = torch.Generator().manual_seed(1)
     images = torch.rand(C, B * world, 3, R, R, generator=g)[:, lo:hi]
-    sets = [C] * (a.steps // C) + ([a.steps % C] if a.steps % C else [])
+    sets = launch_sets(a.steps, C)
 
     def compute(_r, i):
         n = sets[i] if i < len(sets) else C
@@ -461,10 +472,12 @@ def main():
     src = [["source prompt %d of step %d" % (i, j) for i in range(lo, hi)] for j in range(C)]
     tgt = [["target prompt %d of step %d" % (i, j) for i in range(lo, hi)] for j in range(C)]
     torch.manual_seed(4 + rank)  # per-rank noise streams
-    # launch sets: K steps are issued C at a time (the last set may be smaller)
+    # launch sets: K steps are issued at most C at a time, in sets of equal size (launch_sets)
+    sets = launch_sets(a.steps, C)
+    S = max(sets)  # steps of the (largest) launch set: the operating point the line is measured at
     single = (not a.no_single_batch) and C > 1 and a.workload == "c2"
     folded = {n: (images[:n].reshape(n * (hi - lo), 3, R, R), sample_id.repeat(n), sum(src[:n], []), sum(tgt[:n], []))
-              for n in {C, a.steps % C, 1 if single else 0} if n}
+              for n in set(sets) | {1 if single else 0} if n}
 
     def compute(r, n):
         """one launch set of n steps (n * B triplets) on replica r"""
@@ -485,8 +498,6 @@ def main():
             sl = slice(i * B, (i + 1) * B)
             out = gather_outputs((orig[sl], img[sl]), loss[sl])
         return out
-
-    sets = [C] * (a.steps // C) + ([a.steps % C] if a.steps % C else [])
 
     def run_sets(sizes):
         """launch sets in order, up to n_rep of them in flight: one host thread per replica computes, then the main
@@ -524,8 +535,8 @@ def main():
             torch.cuda.synchronize(dev)
             done += n
     while done < a.warmup:
-        gather(0, compute(0, C))
-        done += C
+        gather(0, compute(0, S))
+        done += S
     sync()
     c0 = time.process_time()
     th0 = thread_cpu_seconds()
@@ -566,7 +577,7 @@ def main():
     if ensemble:
         mini_ensemble()
     else:
-        gather(0, compute(0, C))
+        gather(0, compute(0, S))
     sync()
     if rank == 0:
         ips = a.steps * B * world / dt
@@ -595,8 +606,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32" if f32 else ("fp32 (3 x fp16 split products)" if x3 else fmt), "data": "synthetic",
             "config": {"workload": wl["name"], "batch_per_gpu": B, "global_batch": B * world,
-                       "parallelism": "dp%d" % world, "steps_per_launch_set": C, "launch_sets_in_flight_per_gpu": n_rep,
-                       "images_in_flight_per_gpu": B * C * n_rep,
+                       "parallelism": "dp%d" % world, "steps_per_launch_set": S, "launch_sets": sets,
+                       "launch_set_cap": C, "launch_sets_in_flight_per_gpu": n_rep,
+                       "images_in_flight_per_gpu": B * S * n_rep,
                        "distributed": "nccl(RCCL) process group" if dist.is_initialized() else "single process",
                        # CPU seconds of this rank (all threads) per wall second of the timed region: the launching thread
                        # sleeps in blocking-sync events (engine step pacing, cd_engine_synchronize)
@@ -621,9 +633,9 @@ def main():
                          "traffic_source": traffic_source,
                          "operating_point": ("the ensemble's engine calls at their real batch sizes on 4-step chains (skip 95), "
                                              "per-launch HIP events") if ensemble else
-                         "one launch set of %d steps, single stream, per-launch HIP events" % C,
-                         "launches_per_step": n_launch / C, "kernel_ms_per_step": k_ms / C,
-                         "algorithmic_tflop_per_step": k_flops / 1e12 / C,
+                         "one launch set of %d steps, single stream, per-launch HIP events" % S,
+                         "launches_per_step": n_launch / S, "kernel_ms_per_step": k_ms / S,
+                         "algorithmic_tflop_per_step": k_flops / 1e12 / S,
                          "whole_path_frac": ips * wl["flop_per_image"] / 1e12 / (world * peak)},
         }
         if sustained is not None:

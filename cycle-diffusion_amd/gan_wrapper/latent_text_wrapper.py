@@ -156,8 +156,9 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
 
     def _vae_batch(self):
         """images per first-stage call (fp32 / split-mode activations are twice the bytes of the 16-bit ones)"""
-        px = self.VAE_MAX_PIXELS if self.precision == "fp16" else self.VAE_MAX_PIXELS // 2
-        return max(1, px // (self.resolution * self.resolution))
+        px = self.VAE_MAX_PIXELS if getattr(self, "precision", "fp16") == "fp16" else self.VAE_MAX_PIXELS // 2
+        res = getattr(self, "resolution", None) or self.RESOLUTION or 512
+        return max(1, px // (res * res))
 
     def _randn(self, shape, cpu=None):
         """One noise draw. `noise_source` (a callable shape -> CPU tensor; parity tests) replaces the generator: it lets
