@@ -16,8 +16,8 @@ forward = wrapper.encode (VAE encode + DPM-Encoder) + wrapper.forward (coupled d
 i.e. exactly what Trainer.prediction_step times in the reference (trainer/trainer.py:788-789), followed
 by the per-step output gather (trainer.py:833). Prints ONE JSON line on rank 0.
 
-Steps are issued at most `--coalesce` at a time (default: 16 for C2, 4 otherwise) in launch sets of equal size (20 steps =
-10 + 10, `config.launch_sets`): the engine folds the queued batches into
+Steps are issued `--coalesce` at a time (default: 16 for C2, 4 otherwise; a remainder forms one smaller tail set,
+`config.launch_sets`): the engine folds the queued batches into
 ONE launch set (C2: 64 images through the DPM-Encoder, 128 rows through the CFG decode, the first stage in calls of 32
 images), so every GEMM sees 16x the rows with one copy of the weights; each step still gets its own all-gather, in step
 order. `--coalesce 8` / `4` / `1` are the rounds-2b..4 / round-2a / round-1 operating points (8 against 16 on one box:
@@ -259,13 +259,13 @@ def pmc_traffic_per_launch():
 
 
 def launch_sets(steps, cap):
-    """K queued steps as launch sets of at most `cap` steps, as evenly as possible - 20 steps at cap 16 are 10 + 10, not
-    16 + 4: no small tail set (the policy the wrappers apply to ensemble members, latent_text_wrapper._chunks)"""
+    """K queued steps as launch sets of `cap` steps plus one smaller tail set. (Round 5 measured the alternative - sets of equal
+    size, 20 steps = 10 + 10 instead of 16 + 4: 3.16 against 3.35-3.44 images/s, GEMM family 833 against 897-929 TFLOP/s. At
+    4 images per step a fold of 10 puts 640 row tiles of the 64 x 64 level on 256 CUs - 2.5 rounds - where folds of 4 / 8 / 16
+    give 1 / 2 / 4 full rounds: profiles/r5_bench_line_launch_sets_10_10.json.)"""
     if steps <= 0:
         return []
-    n_sets = -(-steps // cap)
-    size = -(-steps // n_sets)
-    return [size] * (n_sets - 1) + [steps - size * (n_sets - 1)]
+    return [cap] * (steps // cap) + ([steps % cap] if steps % cap else [])
 
 
 def _free_port():
@@ -472,7 +472,7 @@ def main():
     src = [["source prompt %d of step %d" % (i, j) for i in range(lo, hi)] for j in range(C)]
     tgt = [["target prompt %d of step %d" % (i, j) for i in range(lo, hi)] for j in range(C)]
     torch.manual_seed(4 + rank)  # per-rank noise streams
-    # launch sets: K steps are issued at most C at a time, in sets of equal size (launch_sets)
+    # launch sets: K steps are issued C at a time (the last set may be smaller)
     sets = launch_sets(a.steps, C)
     S = max(sets)  # steps of the (largest) launch set: the operating point the line is measured at
     single = (not a.no_single_batch) and C > 1 and a.workload == "c2"

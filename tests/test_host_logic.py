@@ -309,19 +309,14 @@ def test_white_box_prefix_reaches_the_engine_as_a_truncated_table(wb):
     assert zshape[1] == n + 1 and k_dec == K and tail == (None if n == K else (K - n, 1, 4, 2, 2))
 
 
-def test_bench_launch_sets_are_balanced():
-    """bench.py issues K queued steps in launch sets of at most `cap` steps and of equal size: no small tail set."""
+def test_bench_launch_sets():
+    """bench.py issues K queued steps in launch sets of `cap` steps plus one tail set (equal-sized sets were measured and are
+    slower: a fold that is not a power of two leaves the 256 CUs a partial round of row tiles)."""
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("_bench", os.path.join(root, "bench.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    assert b.launch_sets(20, 16) == [10, 10]
-    assert b.launch_sets(16, 16) == [16] and b.launch_sets(8, 16) == [8] and b.launch_sets(1, 16) == [1]
-    assert b.launch_sets(17, 16) == [9, 8] and b.launch_sets(33, 16) == [11, 11, 11]
-    assert b.launch_sets(5, 2) == [2, 2, 1] and b.launch_sets(0, 4) == []
-    for k in range(1, 70):
-        for cap in (1, 2, 4, 8, 16):
-            s = b.launch_sets(k, cap)
-            assert sum(s) == k and max(s) <= cap and max(s) - min(s) <= 1 or k % len(s), (k, cap, s)
+    assert b.launch_sets(20, 16) == [16, 4] and b.launch_sets(16, 16) == [16] and b.launch_sets(8, 16) == [8]
+    assert b.launch_sets(33, 16) == [16, 16, 1] and b.launch_sets(5, 2) == [2, 2, 1] and b.launch_sets(0, 4) == []
