@@ -236,16 +236,17 @@ def cpu_baseline_reference():
                       % (ref_import.REF, t_e, n_steps, t_enc, n_steps, t_dec, t_d, per_img)}
 
 
-def pmc_traffic_per_launch():
+def pmc_traffic_per_launch(steps_per_set=16):
     """HBM-side bytes per k_conv_gemm launch from the committed rocprofv3 PMC passes (profiles/README.md):
-    FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over the U-Net forwards of one coalesced C2 launch set (B'=32
-    encode, B'=64 CFG decode), which launch equally often. Returns (bytes, the files it read) - the figure is a
-    constant of the committed profile, not a measurement of this run, and the line says which files it came from;
-    (None, None) when the summaries are absent."""
+    FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE over the U-Net forwards of one coalesced C2 launch set (encode at
+    B' = 4 x steps, guided decode at twice that), which launch equally often. Returns (bytes, the files it read) - the
+    figure is a constant of the committed profile, not a measurement of this run, and the line says which files it came
+    from; (None, None) when no profile of this operating point is committed."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    batches = (4 * steps_per_set, 8 * steps_per_set)
     for rnd in ("r5", "r4", "r3", "r2b"):  # the newest committed pair
         vals, files = [], []
-        for b in (32, 64):
+        for b in batches:
             name = "%s_conv_gemm_traffic_unet_b%d.json" % (rnd, b)
             try:
                 with open(os.path.join(prof, name)) as fh:
@@ -588,7 +589,7 @@ def main():
         # split mode: algorithmic flops (2 M N K of the fp32 conv) against a third of the 16-bit MFMA peak
         peak = PEAK_F32_TFLOPS if f32 else (PEAK_TFLOPS / 3.0 if x3 else PEAK_TFLOPS)
         ach = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        traffic, traffic_source = pmc_traffic_per_launch() if a.workload == "c2" and not (f32 or x3) else (None, None)
+        traffic, traffic_source = pmc_traffic_per_launch(S) if a.workload == "c2" and not (f32 or x3) else (None, None)
         # the ceiling of THIS device on this lease, after the timed region: a bare 16-bit MFMA loop on every CU settles
         # where the package power cap lets it (MI355X, 1400 W: 1.7-1.8 GHz = 1.7-1.8 PFLOP/s)
         sustained = None

@@ -9,11 +9,12 @@ OUT=$ROOT/gpurun_out/prof_bench
 mkdir -p $OUT
 export PYTHONPATH=$ROOT
 cd /tmp
-timeout 900 python $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-single-batch > $OUT/bench.json 2> $OUT/bench.err
+timeout 900 python $ROOT/bench.py --steps 16 --warmup 0 --no-cpu-baseline --no-single-batch > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json | cut -c1-400
-# 8 steps = one launch set timed + one warm-up set + the event-instrumented set: 3 identical launch sets in the trace
-timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- python $ROOT/bench.py --steps 8 --warmup 0 --no-cpu-baseline --no-single-batch > $OUT/stats.log 2>&1
+# 16 steps = one launch set timed + one warm-up set + the event-instrumented set: 3 identical launch sets in the trace
+timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- python $ROOT/bench.py --steps 16 --warmup 0 --no-cpu-baseline --no-single-batch > $OUT/stats.log 2>&1
 python $ROOT/scripts/kernel_breakdown.py $OUT/stats > $OUT/kernel_breakdown.txt 2>&1
+python $ROOT/scripts/kernel_by_grid.py $OUT/stats k_gn_apply k_gn_fold k_layernorm k_attention k_copy_strided > $OUT/stream_kernels_by_grid.txt 2>&1
 head -30 $OUT/kernel_breakdown.txt
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -delete
