@@ -42,4 +42,5 @@ def test_no_kernel_uses_scratch_or_spills_vector_registers():
     assert regs("k_conv_gemm<256, 320, 64, 4, 2, 2,") <= 256
     assert regs("k_conv_gemm<256, 256, 64, 4, 2, 2,") <= 256
     assert regs("k_attention<48, 64, 40, 2, false, 32, 8") <= 128
+    assert regs("k_attention_d40<8>") <= 128  # round 5: the LDS-DMA / 16-row-tail form of the same kernel
     assert regs("k_lin_stream<") <= 256
