@@ -405,8 +405,17 @@ Act attention_f32_fwd(Ctx& c, const Act& qk, const Act& v, int H, int D, float s
   CD_CHECK(c.f32 && qk.f32 && v.f32 && !qk.split && !v.split && qk.C == 2 * H * D && v.C == H * D,
            "attention_f32: operands");
   Act o = alloc_act(c, qk.B, qk.H, qk.W, H * D);
-  launch_attention_f32(c.st, qk.pf(), qk.ld, qk.pf() + H * D, qk.ld, v.pf(), v.ld, o.pf(), o.ld, qk.B, H,
-                       qk.H * qk.W, D, scale, obias);
+  const int T = qk.H * qk.W;
+  if (D <= 160 && (D % 4) == 0 && (qk.ld % 4) == 0 && (v.ld % 4) == 0) {
+    // round 5: heads up to 160 wide (the improved-DDPM AttentionBlocks: 64) on the fp32 flash kernel of st_f32.hip - fp32
+    // matrix instructions instead of one wave per query (3 % of a config-5 step); wider single heads (Ho-DDPM, the KL-f8
+    // first stage: d = C) stay on k_attention_f32
+    launch_flash_f32(c.st, qk.pf(), qk.ld, (int64_t)T * qk.ld, qk.pf() + H * D, qk.ld, (int64_t)T * qk.ld, v.pf(), v.ld,
+                     (int64_t)T * v.ld, o.pf(), o.ld, (int64_t)T * o.ld, qk.B, H, T, T, D, scale * 1.44269504088896340736f, 0,
+                     c.overflow, obias);
+    return o;
+  }
+  launch_attention_f32(c.st, qk.pf(), qk.ld, qk.pf() + H * D, qk.ld, v.pf(), v.ld, o.pf(), o.ld, qk.B, H, T, D, scale, obias);
   return o;
 }
 

@@ -288,7 +288,7 @@ void launch_avgpool2_f32(hipStream_t st, const float* x, float* y, int B, int H,
 // written as the split mode's fp16 pair), GEGLU on a materialised [rows][2 * Nout] projection in packed column order
 void launch_flash_f32(hipStream_t st, const float* q, int ldq, int64_t q_bs, const float* k, int ldk, int64_t k_bs,
                       const float* v, int ldv, int64_t v_bs, float* o, int ldo, int64_t o_bs, int B, int H, int Tq, int Tk,
-                      int D, float qmul, int split, int* overflow);
+                      int D, float qmul, int split, int* overflow, const float* obias = nullptr);
 void launch_layernorm_f32(hipStream_t st, const float* x, int ldx, float* y, int64_t rows, int C, const float* gamma,
                           const float* beta, float eps, int split, int* overflow);
 void launch_geglu_f32(hipStream_t st, const float* h, float* y, int64_t rows, int Nout, int split, int* overflow);

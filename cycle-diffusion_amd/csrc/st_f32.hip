@@ -40,7 +40,8 @@ template <int DB, bool SPLIT>  // head width padded to DB blocks of 32
 __global__ __launch_bounds__(256) void k_flash_f32(const float* __restrict__ q, const float* __restrict__ k,
                                                    const float* __restrict__ v, float* __restrict__ o, int Tq, int Tk,
                                                    int D, int ldq, int ldk, int ldv, int ldo, int64_t q_bs, int64_t k_bs,
-                                                   int64_t v_bs, int64_t o_bs, float qmul, int* overflow) {
+                                                   int64_t v_bs, int64_t o_bs, float qmul, int* overflow,
+                                                   const float* __restrict__ obias) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int DP = 32 * DB, LDK = DP + 1, KT = 32;
   __shared__ float Ks[KT * LDK];
@@ -138,7 +139,11 @@ __global__ __launch_bounds__(256) void k_flash_f32(const float* __restrict__ q, 
       for (int g = 0; g < 4; ++g) {
         const int d = 32 * j + 8 * g + 4 * half;  // 4 consecutive head dims: accumulator registers 4 g .. 4 g + 3
         if (d < D) {
-          const f4 val = {oacc[j][4 * g] * inv, oacc[j][4 * g + 1] * inv, oacc[j][4 * g + 2] * inv, oacc[j][4 * g + 3] * inv};
+          f4 val = {oacc[j][4 * g] * inv, oacc[j][4 * g + 1] * inv, oacc[j][4 * g + 2] * inv, oacc[j][4 * g + 3] * inv};
+          if (obias) {  // value-projection bias: the rows of P sum to 1 (QKVAttentionLegacy with a biased qkv conv)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] += obias[h * D + d + e];
+          }
           if (SPLIT) {
             h4 hi, lo;
 #pragma unroll
@@ -280,7 +285,7 @@ using namespace st_f32_detail;
 
 void launch_flash_f32(hipStream_t st, const float* q, int ldq, int64_t q_bs, const float* k, int ldk, int64_t k_bs,
                       const float* v, int ldv, int64_t v_bs, float* o, int ldo, int64_t o_bs, int B, int H, int Tq, int Tk,
-                      int D, float qmul, int split, int* overflow) {
+                      int D, float qmul, int split, int* overflow, const float* obias) {
   CD_CHECK(D % 4 == 0 && D <= 160 && (ldq % 4) == 0 && (ldk % 4) == 0 && (ldv % 4) == 0 && (ldo % 4) == 0 && Tq > 0 && Tk > 0,
            "flash_f32: D=%d ld %d %d %d %d", D, ldq, ldk, ldv, ldo);
   const dim3 grid((Tq + 127) / 128, H, B), block(256);
@@ -289,9 +294,9 @@ void launch_flash_f32(hipStream_t st, const float* q, int ldq, int64_t q_bs, con
 #define CD_FLASH(N)                                                                                                        \
   do {                                                                                                                     \
     if (split) hipLaunchKernelGGL((k_flash_f32<N, true>), grid, block, 0, st, q, k, v, o, Tq, Tk, D, ldq, ldk, ldv, ldo,  \
-                                  q_bs, k_bs, v_bs, o_bs, qmul, overflow);                                                \
+                                  q_bs, k_bs, v_bs, o_bs, qmul, overflow, obias);                                         \
     else hipLaunchKernelGGL((k_flash_f32<N, false>), grid, block, 0, st, q, k, v, o, Tq, Tk, D, ldq, ldk, ldv, ldo, q_bs, \
-                            k_bs, v_bs, o_bs, qmul, overflow);                                                            \
+                            k_bs, v_bs, o_bs, qmul, overflow, obias);                                                     \
   } while (0)
   switch (DB) {
     case 1: CD_FLASH(1); break;
