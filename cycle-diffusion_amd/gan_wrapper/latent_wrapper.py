@@ -48,6 +48,7 @@ class LatentDiffStochasticWrapper(torch.nn.Module):
         self.custom_steps, self.eta, self.white_box_steps = int(custom_steps), float(eta), int(white_box_steps)
         assert self.eta > 0
         self.noise_on_cpu = bool(noise_on_cpu)
+        self.noise_source = None  # callable(shape) -> tensor: one stream per dataloader batch (main.py --fold) or per sample
         if source_model_type not in MODEL_TYPES:
             raise NotImplementedError(source_model_type)
         udesc_fn, vdesc_fn, ls, le, self.scale_factor, self.use_ema = MODEL_TYPES[source_model_type]
@@ -95,6 +96,8 @@ class LatentDiffStochasticWrapper(torch.nn.Module):
         self._anchor = torch.nn.Parameter(torch.zeros(1, device=self.engine.device), requires_grad=True)
 
     def _randn(self, n, shape):
+        if self.noise_source is not None:
+            return torch.stack([self.noise_source(tuple(shape)) for _ in range(n)], 0).to(self.device, torch.float32)
         if self.noise_on_cpu:  # one tensor per reference draw, in the reference's order
             return torch.stack([torch.randn(shape) for _ in range(n)], 0).to(self.device)
         return torch.randn((n,) + tuple(shape), device=self.device)
