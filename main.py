@@ -28,6 +28,48 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+class BatchStreams:
+    """noise_source of the wrappers: one generator per dataloader batch of a folded call, seeded by (--seed, the batch's
+    first sample id); a draw of shape [sum of batch sizes, ...] is the concatenation of each batch's own draw - exactly what
+    a --fold 1 run draws for that batch, whichever rank or call it lands in"""
+
+    def __init__(self, seed, first_ids, sizes, device):
+        self.sizes, self.device = list(sizes), device
+        self.gens = [torch.Generator(device=device).manual_seed((seed * 1000003 + 7919 * int(i)) % (2 ** 63)) for i in first_ids]
+
+    def __call__(self, shape):
+        assert shape[0] == sum(self.sizes), (shape, self.sizes)
+        return torch.cat([torch.randn((n,) + tuple(shape[1:]), generator=g, device=self.device)
+                          for n, g in zip(self.sizes, self.gens)], 0)
+
+
+def folded_calls(model, batches, fold, seed, device):
+    """The look-ahead loop: `batches` (collated dataloader batches of this rank, in order) run `fold` at a time as ONE
+    model() call; yields (batch dict of the folded call, original images, translated images). Every wrapper of the model
+    that has a `noise_source` hook draws from the per-batch streams above."""
+    wrappers = [w for w in (getattr(model, "gan_wrapper", None), getattr(model, "source_gan_wrapper", None),
+                            getattr(model, "target_gan_wrapper", None)) if w is not None]
+    fold = max(1, int(fold))
+    for c0 in range(0, len(batches), fold):
+        parts = batches[c0:c0 + fold]
+        batch = {"sample_id": torch.cat([p["sample_id"] for p in parts]),
+                 "original_image": torch.cat([p["original_image"] for p in parts])}
+        for k in ("encode_text", "decode_text"):
+            if k in parts[0]:
+                batch[k] = [t for p in parts for t in p[k]]
+        streams = BatchStreams(seed, [int(p["sample_id"][0]) for p in parts], [int(p["sample_id"].shape[0]) for p in parts],
+                               device)
+        for w in wrappers:
+            if hasattr(w, "noise_source"):
+                w.noise_source = streams
+        kw = {"sample_id": batch["sample_id"].to(device), "original_image": batch["original_image"].to(device)}
+        if "encode_text" in batch:
+            kw.update(encode_text=batch["encode_text"], decode_text=batch["decode_text"])
+        with torch.no_grad():
+            (orig, img), _loss, _ = model(**kw)
+        yield batch, orig, img
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg", required=True)
@@ -75,40 +117,8 @@ def main(argv=None):
     import time
     t_start, n_done = time.perf_counter(), 0
     steps = shard_indices(len(ds), a.per_device_eval_batch_size, world, rank)
-    wrappers = [w for w in (getattr(model, "gan_wrapper", None), getattr(model, "source_gan_wrapper", None),
-                            getattr(model, "target_gan_wrapper", None)) if w is not None]
-
-    class BatchStreams:
-        """noise_source of the wrappers: one device generator per dataloader batch of the folded call; a draw of shape
-        [sum of batch sizes, ...] is the concatenation of each batch's own draw (what a --fold 1 run draws for it)"""
-
-        def __init__(self, first_ids, sizes):
-            self.sizes = sizes
-            self.gens = [torch.Generator(device=dev).manual_seed((a.seed * 1000003 + 7919 * int(i)) % (2 ** 63)) for i in first_ids]
-
-        def __call__(self, shape):
-            assert shape[0] == sum(self.sizes), (shape, self.sizes)
-            return torch.cat([torch.randn((n,) + tuple(shape[1:]), generator=g, device=dev)
-                              for n, g in zip(self.sizes, self.gens)], 0)
-
-    fold = max(1, a.fold)
-    for c0 in range(0, len(steps), fold):
-        chunk = steps[c0:c0 + fold]
-        parts = [collate([ds[i] for i in step_idx]) for step_idx in chunk]
-        batch = {"sample_id": torch.cat([p["sample_id"] for p in parts]),
-                 "original_image": torch.cat([p["original_image"] for p in parts])}
-        for k in ("encode_text", "decode_text"):
-            if k in parts[0]:
-                batch[k] = [t for p in parts for t in p[k]]
-        streams = BatchStreams([int(p["sample_id"][0]) for p in parts], [int(p["sample_id"].shape[0]) for p in parts])
-        for w in wrappers:
-            if hasattr(w, "noise_source"):
-                w.noise_source = streams
-        kw = {"sample_id": batch["sample_id"].to(dev), "original_image": batch["original_image"].to(dev)}
-        if "encode_text" in batch:
-            kw.update(encode_text=batch["encode_text"], decode_text=batch["decode_text"])
-        with torch.no_grad():
-            (orig, img), _loss, _ = model(**kw)
+    batches = [collate([ds[i] for i in step_idx]) for step_idx in steps]
+    for batch, orig, img in folded_calls(model, batches, a.fold, a.seed, dev):
         n_done += img.shape[0]
         if a.grid and rank == 0 and len(grid_pairs) < 100:
             grid_pairs.append((orig.detach().clamp(0, 1).cpu(), img.detach().clamp(0, 1).cpu()))
