@@ -32,6 +32,17 @@ def shard_indices(n_items, batch_size, world_size, rank):
     return [idx[g0 + rank * batch_size: g0 + (rank + 1) * batch_size] for g0 in range(0, total, gb)]
 
 
+def shard_padding(n_items, batch_size, world_size, rank):
+    """Same shape as shard_indices: True where a slot holds wrap-around padding (its position in the padded index list is
+    >= n_items) - the rows the reference drops after the gather (`num_total_examples`); a driver that writes per-sample
+    files skips them where they are produced."""
+    if n_items <= 0:
+        return []
+    gb = batch_size * world_size
+    total = ((n_items + gb - 1) // gb) * gb
+    return [[(g0 + rank * batch_size + j) >= n_items for j in range(batch_size)] for g0 in range(0, total, gb)]
+
+
 def global_order(n_items, batch_size, world_size):
     """dataset index of every row of the concatenated per-step gathers (step-major, then rank-major), padding
     included - what distributed_concat + nested_concat produce in the reference's eval loop (trainer.py:825-840)."""

@@ -9,12 +9,13 @@ L2 against the input; CLIP / directional CLIP when the config selects `ranker = 
   python -m torch.distributed.run --nproc-per-node 8 main.py ...        # one process per GPU
 
 `--fold N` is the engine's look-ahead: N consecutive dataloader batches of this rank run as ONE model() call (the operating
-point bench.py's headline is measured at: 8 batches of 4 = 32 images through the DPM-Encoder, 64 rows through the guided
+point bench.py's headline is measured at: 16 batches of 4 = 64 images through the DPM-Encoder, 128 rows through the guided
 decode), and the outputs are split back per sample. The reference's driver issues one batch per call
 (trainer/trainer.py:788-833 with --per_device_eval_batch_size 4, README.md:153); the samples of a batch are independent, so
-folding changes no result beyond kernel summation order. To make that checkable, every dataloader batch owns its noise
-stream (a device generator seeded by --seed and the batch's first sample id): a run's images do not depend on --fold, on the
-number of ranks, or on which rank a batch lands.
+folding changes no result beyond kernel summation order. To make that checkable, every SAMPLE owns its noise stream (a
+device generator seeded by --seed and the sample id): a run's images do not depend on --fold, on the batch size, on the
+number of ranks, or on which rank / batch / slot a sample lands in - including the duplicates the sampler's wrap-around
+padding creates (they reproduce the original's image and are not written a second time).
 """
 import argparse
 import json
@@ -28,37 +29,45 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-class BatchStreams:
-    """noise_source of the wrappers: one generator per dataloader batch of a folded call, seeded by (--seed, the batch's
-    first sample id); a draw of shape [sum of batch sizes, ...] is the concatenation of each batch's own draw - exactly what
-    a --fold 1 run draws for that batch, whichever rank or call it lands in"""
+class SampleStreams:
+    """noise_source of the wrappers: one generator per SAMPLE of a (folded) call, seeded by (--seed, sample id); a draw of
+    shape [n samples, ...] is the concatenation of each sample's own [1, ...] draw - what that sample draws in any other
+    call, batch, slot or rank (round-5 advisor: per-batch streams keyed by the batch's first id made a wrap-around duplicate
+    that lands in another batch position draw other noise than its original, and then overwrite it)"""
 
-    def __init__(self, seed, first_ids, sizes, device):
-        self.sizes, self.device = list(sizes), device
-        self.gens = [torch.Generator(device=device).manual_seed((seed * 1000003 + 7919 * int(i)) % (2 ** 63)) for i in first_ids]
+    def __init__(self, seed, sample_ids, device):
+        self.device = device
+        self.gens = [torch.Generator(device=device).manual_seed((seed * 1000003 + 7919 * int(i)) % (2 ** 63))
+                     for i in sample_ids]
 
     def __call__(self, shape):
-        assert shape[0] == sum(self.sizes), (shape, self.sizes)
-        return torch.cat([torch.randn((n,) + tuple(shape[1:]), generator=g, device=self.device)
-                          for n, g in zip(self.sizes, self.gens)], 0)
+        assert shape[0] == len(self.gens), (shape, len(self.gens))
+        return torch.cat([torch.randn((1,) + tuple(shape[1:]), generator=g, device=self.device) for g in self.gens], 0)
 
 
 def folded_calls(model, batches, fold, seed, device):
-    """The look-ahead loop: `batches` (collated dataloader batches of this rank, in order) run `fold` at a time as ONE
-    model() call; yields (batch dict of the folded call, original images, translated images). Every wrapper of the model
-    that has a `noise_source` hook draws from the per-batch streams above."""
+    """The look-ahead loop: `batches` (an iterable of collated dataloader batches of this rank, in order; pulled `fold` at a
+    time, so a generator keeps host memory at one folded call) run `fold` at a time as ONE model() call; yields (batch dict of
+    the folded call, original images, translated images). Every wrapper of the model that has a `noise_source` hook draws
+    from the per-sample streams above."""
+    import itertools
     wrappers = [w for w in (getattr(model, "gan_wrapper", None), getattr(model, "source_gan_wrapper", None),
                             getattr(model, "target_gan_wrapper", None)) if w is not None]
     fold = max(1, int(fold))
-    for c0 in range(0, len(batches), fold):
-        parts = batches[c0:c0 + fold]
+    it = iter(batches)
+    while True:
+        parts = list(itertools.islice(it, fold))
+        if not parts:
+            break
         batch = {"sample_id": torch.cat([p["sample_id"] for p in parts]),
                  "original_image": torch.cat([p["original_image"] for p in parts])}
         for k in ("encode_text", "decode_text"):
             if k in parts[0]:
                 batch[k] = [t for p in parts for t in p[k]]
-        streams = BatchStreams(seed, [int(p["sample_id"][0]) for p in parts], [int(p["sample_id"].shape[0]) for p in parts],
-                               device)
+        for k in ("is_padding",):  # host-side bookkeeping of the driver: passed through, never handed to the model
+            if k in parts[0]:
+                batch[k] = [t for p in parts for t in p[k]]
+        streams = SampleStreams(seed, batch["sample_id"].tolist(), device)
         for w in wrappers:
             if hasattr(w, "noise_source"):
                 w.noise_source = streams
@@ -80,7 +89,8 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--fold", type=int, default=1,
                     help="look-ahead: run N consecutive batches of this rank as one model() call (larger GEMMs; bench.py's "
-                         "headline operating point is --per_device_eval_batch_size 4 --fold 8); results per image are those of "
+                         "headline operating point is --per_device_eval_batch_size 4 --fold 16; under the reference's own Trainer "
+                         "the same launch sets are reached with --per_device_eval_batch_size 64); results per image are those of "
                          "--fold 1 up to kernel summation order")
     ap.add_argument("--grid", action="store_true",
                     help="also write the reference's multi_image pair grids (original | translated, 8 per row)")
@@ -100,7 +110,7 @@ def main(argv=None):
 
     import cycle_diffusion_amd  # noqa: F401
     from cycle_diffusion_amd.data.triplets import TripletDataset, collate
-    from cycle_diffusion_amd.parallel import shard_indices
+    from cycle_diffusion_amd.parallel import shard_indices, shard_padding
     from cycle_diffusion_amd.utils import metrics
     from cycle_diffusion_amd.utils.config_utils import get_config
     from cycle_diffusion_amd.utils.program_utils import get_model
@@ -117,12 +127,22 @@ def main(argv=None):
     import time
     t_start, n_done = time.perf_counter(), 0
     steps = shard_indices(len(ds), a.per_device_eval_batch_size, world, rank)
-    batches = [collate([ds[i] for i in step_idx]) for step_idx in steps]
-    for batch, orig, img in folded_calls(model, batches, a.fold, a.seed, dev):
+    pads = shard_padding(len(ds), a.per_device_eval_batch_size, world, rank)
+
+    def batches():  # decoded and collated as the loop pulls them: host memory holds one folded call, not the shard
+        for step_idx, pad in zip(steps, pads):
+            b = collate([ds[i] for i in step_idx])
+            b["is_padding"] = list(pad)
+            yield b
+
+    grid_cap = 100 * a.per_device_eval_batch_size  # the reference keeps 100 dataloader batches for its grids
+    for batch, orig, img in folded_calls(model, batches(), a.fold, a.seed, dev):
         n_done += img.shape[0]
-        if a.grid and rank == 0 and len(grid_pairs) < 100:
+        if a.grid and rank == 0 and sum(p[0].shape[0] for p in grid_pairs) < grid_cap:
             grid_pairs.append((orig.detach().clamp(0, 1).cpu(), img.detach().clamp(0, 1).cpu()))
         for j in range(img.shape[0]):
+            if batch["is_padding"][j]:  # wrap-around padding of the last global batch: its original is written elsewhere
+                continue
             o, g = orig[j].clamp(0, 1).cpu(), img[j].clamp(0, 1).cpu()
             sid = int(batch["sample_id"][j])
             row = {"sample_id": sid, "psnr": float(metrics.calculate_psnr(g, o)),
@@ -147,7 +167,7 @@ def main(argv=None):
         from cycle_diffusion_amd.utils.visualize import visualize
         visualize((torch.cat([p[0] for p in grid_pairs]), torch.cat([p[1] for p in grid_pairs])), "eval", a.output_dir, 0)
     if rank == 0:
-        rows = list({r["sample_id"]: r for r in rows}.values())  # the sampler's wrap-around padding repeats samples
+        assert len({r["sample_id"] for r in rows}) == len(rows)  # padding rows were skipped where they were produced
         rows.sort(key=lambda r: r["sample_id"])
         summary = {k: sum(r[k] for r in rows) / max(1, len(rows)) for k in ("psnr", "ssim", "l2")}
         with open(os.path.join(a.output_dir, "metrics.json"), "w") as fh:

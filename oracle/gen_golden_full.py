@@ -6,6 +6,7 @@
   python -m oracle.gen_golden_full --only ldm_uncond  (~6 min; the unconditional-LDM U-Net at full size, latent side)
   python -m oracle.gen_golden_full --only c2ens   (~25 min; the SD wrapper's ensemble loops, SD-sized nets at 256 x 256)
   python -m oracle.gen_golden_full --only c5      (~30 min; the same with the reference's full 1000 / 850 / 100 chain)
+  python -m oracle.gen_golden_full --only c2b4    (~2 h; config 2 with FOUR triplets per reference call, skip 20, scales [1, 3])
 
 One (image, source-text, target-text) triplet per BASELINE configuration, run the way the reference's
 text wrapper composes it (stable_diffusion_stochastic_text_wrapper.py:169-249): VAE encode -> posterior
@@ -153,6 +154,63 @@ def gen_c2_ensemble():
          cpu_threads=torch.get_num_threads())
 
 
+def gen_c2_b4():
+    """A second, independent pin of BASELINE config 2 at the reference harness's own batch size: FOUR (image, source text,
+    target text) triplets in ONE call of every reference function (README.md:153 `--per_device_eval_batch_size 4`;
+    trainer/trainer.py:788-789), the way SDStochasticTextWrapper composes them (stable_diffusion_stochastic_text_wrapper.py:
+    169-206 encode, :142-167 generate) with `skip_steps = [20]`, encoder scale 1 and decoder scales [1, 3] -> 2 candidates per
+    triplet. Other seeds than c2_sd512_e2e for the images, the twelve contexts and the noise; same synthetic networks. Draws:
+    one posterior sample [4, 4, 64, 64], randn_like(x0), one randn [4, 4, 64, 64] per sample_xt_next (ddim.py:479, 599).
+    ~2 h on 6 threads (79 encoder forwards at B = 4, 79 decoder forwards at B = 4 and 79 at B = 8)."""
+    ref_import.setup()
+    from ldm.modules.distributions.distributions import DiagonalGaussianDistribution
+    Sampler = ref_import.ddim_sampler_cls()
+    res, steps, eta, wb, B = 512, 99, 0.1, 100, 4
+    skip, dec_scales = 20, [1.0, 3.0]
+    seeds = dict(unet=SEEDS["unet"], vae=SEEDS["vae"], image=[101, 102, 103, 104], c_src=[111, 112, 113, 114],
+                 c_tgt=[121, 122, 123, 124], uc=131, noise=2024)
+    t0 = time.time()
+    with torch.no_grad():
+        u = build_ref_sd_unet(SD_UNET)
+        uns, _ = load_synth(u, seeds["unet"])
+        v = RefVAE(FULL_VAE)
+        vns, _ = load_synth(v, seeds["vae"])
+        shim = ref_import.LatentShim(u)
+        lat = res // 8
+        image = torch.cat([torch.rand((1, 3, res, res), generator=torch.Generator().manual_seed(s))
+                           for s in seeds["image"]], 0)
+        c_src = torch.cat([rnd((1, 77, 768), s) for s in seeds["c_src"]], 0)
+        c_tgt = torch.cat([rnd((1, 77, 768), s) for s in seeds["c_tgt"]], 0)
+        uc = rnd((1, 77, 768), seeds["uc"]).repeat(B, 1, 1)  # get_condition: bs * [""] (sd_wrapper:28-36)
+        torch.manual_seed(seeds["noise"])
+        post = DiagonalGaussianDistribution(v.moments((image - 0.5) * 2.0))
+        x0 = post.sample() * 0.18215
+        print("c2_b4: vae encode done", time.time() - t0, flush=True)
+        with ref_import.quiet():
+            z_list = Sampler(shim).ddpm_ddim_encoding(steps, conditioning=c_src, batch_size=B, shape=(4, lat, lat),
+                                                      eta=eta, white_box_steps=wb, skip_steps=skip, verbose=False, x0=x0,
+                                                      unconditional_guidance_scale=1, unconditional_conditioning=uc)
+        z = torch.stack(z_list, dim=1)
+        assert z.shape[1] == wb - skip
+        print("c2_b4: encode done", time.time() - t0, flush=True)
+        lats, imgs = [], []
+        for sc in dec_scales:
+            with ref_import.quiet():
+                x, _ = Sampler(shim).sample_with_eps(steps, z[:, 1:], conditioning=c_tgt, batch_size=B,
+                                                     shape=(4, lat, lat), eta=eta, verbose=False, x_T=z[:, 0],
+                                                     skip_steps=skip, unconditional_guidance_scale=sc,
+                                                     unconditional_conditioning=uc)
+            lats.append(x)
+            imgs.append(torch.cat([(v.decode(x[i:i + 1] / 0.18215) + 1.0) / 2.0 for i in range(B)], 0))
+            print("c2_b4: scale", sc, "decoded", time.time() - t0, flush=True)
+    slots = [0, 1, 40, wb - skip - 1]
+    save("c2_sd512_b4_e2e", unet_names=json.dumps(uns), vae_names=json.dumps(vns), seeds=json.dumps(seeds), steps=steps,
+         eta=eta, white_box_steps=wb, skip_steps=np.asarray([skip]), dec_scales=np.asarray(dec_scales), x0=x0,
+         z_sub=z[:, slots], z_sub_slots=np.asarray(slots), z_norms=z.flatten(2).norm(dim=2),
+         lat=torch.stack(lats, 0), img=torch.stack(imgs, 0).to(torch.float16), cpu_seconds=time.time() - t0,
+         cpu_threads=torch.get_num_threads())
+
+
 LDM_UNCOND_UNET = dict(image_size=64, in_channels=3, out_channels=3, model_channels=224, attention_resolutions=[8, 4, 2],
                        num_res_blocks=2, channel_mult=[1, 2, 3, 4], num_head_channels=32)  # celeba256 / ffhq256 config.yaml:17-34
 
@@ -252,3 +310,5 @@ if __name__ == "__main__":
         gen_c2_ensemble()
     if a.only == "ldm_uncond":  # ~6 min
         gen_ldm_uncond_full()
+    if a.only == "c2b4":  # ~2 h: only on request
+        gen_c2_b4()

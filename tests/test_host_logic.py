@@ -323,14 +323,17 @@ def test_bench_launch_sets():
 
 
 def test_main_fold_look_ahead_is_invariant_to_fold_and_sharding():
-    """main.py's look-ahead (`--fold N`: N dataloader batches in one model() call) with one noise stream per dataloader
-    batch: the output of every sample must be BIT-identical for fold 1 / 2 / 3 and whether the batches run on one rank or
-    are sharded over two (ShardSampler order) - checked with a stand-in model whose output is the image plus the noise its
-    wrapper drew through the `noise_source` hook (CPU; the GPU twin is test_main_driver_fold_look_ahead_matches_...)."""
+    """main.py's look-ahead (`--fold N`: N dataloader batches in one model() call) with one noise stream per SAMPLE: the
+    output of every sample must be BIT-identical for any fold, any batch size, and whether the batches run on one rank or
+    are sharded over two (ShardSampler order) - including batch sizes that do not divide the dataset, where the sampler's
+    wrap-around duplicates land in other batch positions than their originals (round-5 advisor: with per-batch streams
+    n = 10, bs = 4, world 1 vs 2 gave different images for samples 2..5 and the duplicate overwrote the original). Checked
+    with a stand-in model whose output is the image plus the noise its wrapper drew through the `noise_source` hook (CPU;
+    the GPU twin is test_main_driver_fold_look_ahead_matches_...)."""
     import importlib.util
     import os
     import torch
-    from cycle_diffusion_amd.parallel import shard_indices
+    from cycle_diffusion_amd.parallel import shard_indices, shard_padding
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("_main", os.path.join(root, "main.py"))
     drv = importlib.util.module_from_spec(spec)
@@ -350,26 +353,36 @@ def test_main_fold_look_ahead_is_invariant_to_fold_and_sharding():
             tag = torch.tensor([float(len(t)) for t in decode_text]).view(-1, 1, 1, 1)
             return (original_image, original_image + n1 + 0.5 * n2 + tag), torch.zeros(original_image.shape[0]), {}
 
-    n_items, bs = 10, 2
+    n_items = 10
     g = torch.Generator().manual_seed(0)
     imgs = torch.rand(n_items, 3, 4, 4, generator=g)
 
-    def collate(idx):
-        return {"sample_id": torch.tensor(idx), "original_image": imgs[idx],
+    def collate(idx, pad):
+        return {"sample_id": torch.tensor(idx), "original_image": imgs[idx], "is_padding": list(pad),
                 "encode_text": ["s%d" % i for i in idx], "decode_text": ["t" * (i + 1) for i in idx]}
 
-    def run(fold, world):
-        out = {}
+    def run(fold, world, bs):
+        out, n_pad = {}, 0
         for rank in range(world):
-            batches = [collate(ix) for ix in shard_indices(n_items, bs, world, rank)]
+            # a generator, as main.py hands it over: the loop must pull `fold` batches at a time
+            batches = (collate(ix, pd) for ix, pd in zip(shard_indices(n_items, bs, world, rank),
+                                                         shard_padding(n_items, bs, world, rank)))
             for batch, orig, img in drv.folded_calls(M(), batches, fold, 42, torch.device("cpu")):
                 assert torch.equal(orig, imgs[batch["sample_id"]])
                 for j, sid in enumerate(batch["sample_id"].tolist()):
-                    out.setdefault(sid, img[j])
-                    assert torch.equal(out[sid], img[j])  # wrap-around duplicates carry the same stream
+                    if batch["is_padding"][j]:  # main.py skips these rows; they must still REPRODUCE their original
+                        n_pad += 1
+                        pads.append((sid, img[j]))
+                        continue
+                    assert sid not in out  # every real sample is produced exactly once
+                    out[sid] = img[j]
+        assert n_pad == -(-n_items // (bs * world)) * bs * world - n_items
         return torch.stack([out[i] for i in range(n_items)])
 
-    base = run(1, 1)
+    pads = []
+    base = run(1, 1, 2)
     assert (base - imgs).abs().max() > 0.1  # noise really entered
-    for fold, world in ((2, 1), (3, 1), (5, 1), (1, 2), (2, 2)):
-        assert torch.equal(run(fold, world), base), (fold, world)
+    for fold, world, bs in ((2, 1, 2), (3, 1, 2), (5, 1, 2), (1, 2, 2), (2, 2, 2), (1, 1, 4), (1, 2, 4), (2, 2, 4), (3, 1, 3),
+                            (1, 2, 3), (16, 1, 4), (1, 1, 7)):
+        assert torch.equal(run(fold, world, bs), base), (fold, world, bs)
+    assert pads and all(torch.equal(img, base[sid]) for sid, img in pads)
