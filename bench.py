@@ -288,10 +288,53 @@ def self_launch(n_ranks, argv):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
         t0 = time.time()
-        rc = subprocess.call(cmd, env=env, cwd=ROOT)
-        if rc == 0 or time.time() - t0 > 60:  # a rendezvous that lost the race for its port fails within seconds
+        p = subprocess.run(cmd, env=env, cwd=ROOT, stderr=subprocess.PIPE, text=True)
+        rc = p.returncode
+        sys.stderr.write(p.stderr)
+        # retry ONLY a rendezvous that lost the race for its port (fails within seconds, and says so); a bad argument or an
+        # import error must not run - and print its error - three times
+        lost_port = any(k in p.stderr for k in ("EADDRINUSE", "Address already in use", "address already in use",
+                                                "failed to bind", "RendezvousConnectionError", "DistNetworkError"))
+        if rc == 0 or time.time() - t0 > 60 or not lost_port:
             break
     return rc
+
+
+def ranks_seen_by_gather(rank, world, dev):
+    """every rank's id through one all-gather on the job's process group: the line proves the collective saw N ranks"""
+    if not dist.is_initialized():
+        return [rank]
+    mine = torch.tensor([rank], device=dev, dtype=torch.int64)
+    outs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(outs, mine)
+    return [int(o.item()) for o in outs]
+
+
+def bf16_leg(steps=16):
+    """BASELINE.json's C2 line names bf16 storage; the headline runs the fp16 build. The bf16 build of the same
+    sources (lib/libcyclediff_bf16.so, built by __graft_entry__.build()) is measured here beside it: one more bench.py process
+    on that library (CYCLEDIFF_LIB), `--steps 16` = one full launch set, no other legs. Its parity floor (34 dB against the
+    reference's image; the fp16 build holds 50) is what tests/test_gpu_e2e_fullsize.py::
+    test_c2_sd_v14_512_end_to_end_on_the_bf16_library runs on the same library."""
+    lib = os.path.join(ROOT, "cycle-diffusion_amd", "lib", "libcyclediff_bf16.so")
+    if not os.path.exists(lib):
+        return {"error": "lib/libcyclediff_bf16.so has not been built (__graft_entry__.build())"}
+    env = dict(os.environ, CYCLEDIFF_LIB=lib)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", "0", "--no-cpu-baseline",
+           "--no-single-batch", "--no-bf16"]
+    try:
+        p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        line = json.loads(p.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001 - a side leg never fails the headline
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    assert line["dtype"] == "bf16", line["dtype"]
+    return {"value": line["value"], "unit": "images/s", "steps": line["steps"], "ms_per_step": line["ms_per_step"],
+            "dtype": line["dtype"], "gemm_family_tflops": line["roofline"]["achieved"], "psnr_floor": 34.0,
+            "psnr_floor_unit": "dB image PSNR vs the reference's CPU run on the C2 fixture (fp16 build: 50)",
+            "psnr_test": "tests/test_gpu_e2e_fullsize.py::test_c2_sd_v14_512_end_to_end_on_the_bf16_library",
+            "library": "cycle-diffusion_amd/lib/libcyclediff_bf16.so (-DCD_ACT_FP16=0), same command with CYCLEDIFF_LIB"}
 
 
 def dry_main(a, wl, rank, world):
@@ -345,6 +388,7 @@ def dry_main(a, wl, rank, world):
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    ranks_seen = ranks_seen_by_gather(rank, world, torch.device("cpu"))
     res = None
     if rank == 0:
         assert len(seen) == a.steps and all(n == B * world for n in seen), seen  # one full global batch per step
@@ -352,7 +396,7 @@ def dry_main(a, wl, rank, world):
         res = {"metric": wl["metric"], "value": a.steps * B * world / dt, "unit": "images/s", "n_gpus": world,
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry run: no engine call, host plumbing only",
-               "dry_run": True,
+               "dry_run": True, "ranks_seen": ranks_seen, "host_threads_per_rank": torch.get_num_threads(),
                "config": {"workload": wl["name"], "batch_per_gpu": B, "global_batch": B * world,
                           "parallelism": "dp%d" % world, "steps_per_launch_set": C,
                           "distributed": "gloo process group" if dist.is_initialized() else "single process"}}
@@ -373,6 +417,7 @@ def main():
                     "BASELINE batch: 4 for C2, README.md:153; 16 for C3, README.md:195)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-batch", action="store_true", help="skip the extra launch-sets-of-one-step measurement")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-library leg (c2 default run on one GPU)")
     ap.add_argument("--single-steps", type=int, default=2, help="steps of the single-batch measurement (c2 default run)")
     ap.add_argument("--coalesce", type=int, default=0,
                     help="steps folded into one engine launch set (same images in flight as that many replicas, ONE "
@@ -404,11 +449,11 @@ def main():
     a.force_dist = a.force_dist or a.self_launch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # host-side weight synthesis / oracle: stay inside the CPU quota, shared by the ranks of the node
+    torch.set_num_threads(max(1, host_cores() // max(1, world)))
     if a.dry_run:
         assert world == a.gpus, "WORLD_SIZE %d does not match --gpus %d" % (world, a.gpus)
         return dry_main(a, wl, rank, world)
-    # host-side weight synthesis / oracle: stay inside the CPU quota, shared by the ranks of the node
-    torch.set_num_threads(max(1, host_cores() // max(1, world)))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 or world > 1 or a.force_dist:
         assert world == a.gpus, "WORLD_SIZE %d does not match --gpus %d" % (world, a.gpus)
@@ -553,6 +598,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(out[0][1]).all()
+    ranks_seen = ranks_seen_by_gather(rank, world, dev)
 
     # BASELINE's literal operating point beside the folded one: launch sets of ONE step (a batch of B triplets per
     # engine call, B' = B through the DPM-Encoder), timed the same way on every rank
@@ -606,6 +652,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32" if f32 else ("fp32 (3 x fp16 split products)" if x3 else fmt), "data": "synthetic",
+            "ranks_seen": ranks_seen,  # rank ids through one all-gather on the job's process group
             "config": {"workload": wl["name"], "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world, "steps_per_launch_set": S, "launch_sets": sets,
                        "launch_set_cap": C, "launch_sets_in_flight_per_gpu": n_rep,
@@ -663,6 +710,9 @@ def main():
             res["single_batch"] = {"value": sv, "unit": "images/s", "steps": a.single_steps,
                                    "ms_per_step": 1e3 * single_dt / a.single_steps, "images_in_flight_per_gpu": B,
                                    "whole_path_frac": sv * wl["flop_per_image"] / 1e12 / (world * peak)}
+        if (world == 1 and not a.no_bf16 and a.workload == "c2" and not (f32 or x3) and fmt == "fp16"
+                and not os.environ.get("CYCLEDIFF_LIB") and not dist.is_initialized()):
+            res["bf16"] = bf16_leg()
         if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
             ref = cpu_baseline_reference()
             if ref is not None:  # the reference itself; the oracle port's forward-extrapolated figure beside it

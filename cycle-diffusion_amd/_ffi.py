@@ -69,6 +69,8 @@ SIGNATURES = {
     "cd_dpm_encode": [_VP, _I, _I, _VP, _VP, _VP, _I, _F, _I, _I, _VP, _VP, _U64, _I, _VP],
     "cd_ddim_decode": [_VP, _I, _I, _VP, _I, _I, _VP, _VP, _I, _F, _I, _I, _VP, _VP, _U64, _VP],
     "cd_ddim_decode_v": [_VP, _I, _I, _VP, _I, _I, _VP, _VP, _I, _VP, _I, _I, _VP, _VP, _U64, _VP],
+    "cd_cycle_translate": [_VP, _I, _I, _VP, _VP, _VP, _F, _VP, _VP, _F, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _U64, _I, _VP,
+                           _VP],
     "cd_pix_refine": [_VP, _I, _I, _VP, _I, _I, _VP, _VP, _U64],
     "cd_op_pack_conv_weight": [_VP, _VP, _I, _I, _I, _I, _I, C.POINTER(_VP), C.POINTER(_I), C.POINTER(_I)],
     "cd_op_free": [_VP, _VP],

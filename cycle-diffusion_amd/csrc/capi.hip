@@ -625,6 +625,101 @@ int cd_ddim_decode_v(cd_handle h, int net, int sched_kind, const float* z, int z
   CD_API_END
 }
 
+// The coupled source -> target loop (north_star): DPM-Encoder step k and decode step k evaluate the SAME network at the SAME
+// timestep, and the decode step only needs eps_k AFTER its forward - so both ride in one U-Net batch
+//   [ encoder rows (B, or uncond B | cond B under encoder guidance) | decoder rows (Bd = n_dec * B, or uncond Bd | cond Bd) ]
+// followed by the encoder's step kernel (x_{k-1}, eps_k -> z) and then the decoder's (consumes eps_k). 99 forwards of
+// B + 2 Bd rows instead of 99 of B and 99 of 2 Bd. Per-sample arithmetic is that of cd_dpm_encode followed by cd_ddim_decode(_v).
+int cd_cycle_translate(cd_handle h, int net, int sched_kind, const float* x0, const float* enc_ctx_c,
+                       const float* enc_ctx_uc, float enc_guidance, const float* dec_ctx_c, const float* dec_ctx_uc,
+                       float dec_guidance, const float* dec_guidance_per_sample, int ctx_len, int B, int n_dec, int K,
+                       const cd_step_coef* coef_enc_host, const cd_step_coef* coef_dec_host, const float* noise,
+                       uint64_t seed, int last_uses_x0, float* z_out, float* x_out) {
+  CD_API_BEGIN
+  enter_engine(h);
+  CD_CHECK(h && x0 && coef_enc_host && coef_dec_host && z_out && x_out && B > 0 && n_dec > 0 && K > 0, "bad argument");
+  ArenaScope arena_scope(h->arena);
+  UNet* u = get_unet(h, net);
+  const int Bd = B * n_dec;
+  const int C = u->desc.in_channels, HW = u->image_size * u->image_size, cpad = u->in_cpad, out_ld = u->out_channels;
+  const bool f32 = u->f32;
+  Guidance ge = resolve_guidance(enc_ctx_c, enc_ctx_uc, enc_guidance);
+  Guidance gd = resolve_guidance(dec_ctx_c, dec_ctx_uc, dec_guidance_per_sample ? 2.0f : dec_guidance);
+  if (dec_guidance_per_sample) CD_CHECK(gd.cfg, "per-sample guidance needs the classifier-free-guidance batch (both contexts)");
+  CD_CHECK(sched_kind == CD_SCHED_DDIM || (!ge.cfg && !gd.cfg), "classifier-free guidance is only implemented for sched_kind = CD_SCHED_DDIM");
+  const bool has_ctx = enc_ctx_c || enc_ctx_uc;
+  CD_CHECK(has_ctx == (dec_ctx_c || dec_ctx_uc), "cd_cycle_translate: contexts for both passes or for neither");
+  const int Ben = ge.cfg ? 2 * B : B, Bdn = gd.cfg ? 2 * Bd : Bd, Bn = Ben + Bdn;
+  Ctx c = h->ctx();
+  if (has_ctx) {
+    const int Dc = u->desc.context_dim;
+    CD_CHECK(Dc > 0 && ctx_len > 0, "network has no cross-attention but a context was given");
+    // one context tensor in batch-row order: [enc (uncond | cond) | dec (uncond | cond)]
+    const size_t esz = f32 ? 4 : 2, per = (size_t)ctx_len * Dc;
+    char* cx = (char*)h->arena.alloc((size_t)Bn * per * esz);
+    auto put = [&](const float* src, int rows, size_t row0) {
+      if (f32) HIP_CHECK(hipMemcpyAsync(cx + row0 * per * 4, src, (size_t)rows * per * 4, hipMemcpyDeviceToDevice, h->st));
+      else launch_nchw_to_nhwc(h->st, src, (bf16_t*)cx + row0 * per, rows * ctx_len, Dc, 1, Dc, 1.f, 0.f, 0);
+    };
+    if (ge.cfg) { put(enc_ctx_uc, B, 0); put(enc_ctx_c, B, B); } else put(ge.ctx_single, B, 0);
+    if (gd.cfg) { put(dec_ctx_uc, Bd, Ben); put(dec_ctx_c, Bd, Ben + Bd); } else put(gd.ctx_single, Bd, Ben);
+    u->set_context(c, (const bf16_t*)cx, Bn, ctx_len);
+  } else {
+    CD_CHECK(u->desc.context_dim <= 0 || !u->desc.use_spatial_transformer, "network expects a cross-attention context");
+  }
+  const size_t esz = f32 ? 4 : 2;
+  const int64_t chw = (int64_t)C * HW, n = (int64_t)B * chw;
+  float* xt_e = (float*)h->arena.alloc((size_t)B * chw * 4);
+  float* xt_d = (float*)h->arena.alloc((size_t)Bd * chw * 4);
+  char* xin = (char*)h->arena.alloc((size_t)Bn * HW * cpad * esz);
+  HIP_CHECK(hipMemsetAsync(xin, 0, (size_t)Bn * HW * cpad * esz, h->st));
+  float* eh = (float*)h->arena.alloc((size_t)Bn * HW * out_ld * 4);
+  const size_t row_in = (size_t)HW * cpad * esz;  // bytes of one sample of the network input
+  bf16_t* xin_e = f32 ? nullptr : (bf16_t*)xin;
+  bf16_t* xin_d = f32 ? nullptr : (bf16_t*)(xin + (size_t)Ben * row_in);
+  EpsHat eh_e, eh_d;
+  eh_e.p = eh; eh_e.sb = (int64_t)HW * out_ld; eh_e.sc = 1; eh_e.sp = out_ld; eh_e.cfg = ge.cfg ? 1 : 0; eh_e.g = enc_guidance;
+  eh_d = eh_e; eh_d.p = eh + (int64_t)Ben * HW * out_ld; eh_d.cfg = gd.cfg ? 1 : 0; eh_d.g = dec_guidance;
+  eh_d.gvec = dec_guidance_per_sample;
+  StepCoef* tab_e = upload_coef(h, coef_enc_host, K + 1);
+  StepCoef* tab_d = upload_coef(h, coef_dec_host, K);
+  const int64_t zbs = (int64_t)(K + 1) * chw;
+  // x_T (ddim.py:477-479), z[:, 0]; the decoder starts from the same tensor (sd_wrapper:153), once per decoder scale
+  launch_init_xt(h->st, x0, noise, seed, 0u, xt_e, z_out, zbs, B, C, HW, tab_e, K, xin_e, cpad, ge.cfg ? 1 : 0);
+  for (int j = 0; j < n_dec; ++j)
+    HIP_CHECK(hipMemcpyAsync(xt_d + (int64_t)j * n, xt_e, (size_t)n * 4, hipMemcpyDeviceToDevice, h->st));
+  if (!f32) launch_nchw_to_nhwc(h->st, xt_d, xin_d, Bd, C, HW, cpad, 1.f, 0.f, gd.cfg ? 1 : 0);
+  // rows that repeat the rows just ahead of them (the decoder's cond half repeats its uncond half): the network computes
+  // everything ahead of the first cross-attention once for them - only when the encoder half has no such pair of its own
+  const int dup_tail = (gd.cfg && !ge.cfg) ? Bd : 0;
+  for (int i = 0; i < K; ++i) {
+    const int k = K - 1 - i;
+    if (f32) {
+      float* xf = (float*)xin;
+      launch_nchw_to_nhwc_f32(h->st, xt_e, xf, B, C, HW, cpad, 1.f, 0.f, u->x3 ? 1 : 0, h->overflow_dev);
+      if (ge.cfg) launch_nchw_to_nhwc_f32(h->st, xt_e, xf + (size_t)B * HW * cpad, B, C, HW, cpad, 1.f, 0.f, u->x3 ? 1 : 0, h->overflow_dev);
+      float* xd = xf + (size_t)Ben * HW * cpad;
+      launch_nchw_to_nhwc_f32(h->st, xt_d, xd, Bd, C, HW, cpad, 1.f, 0.f, u->x3 ? 1 : 0, h->overflow_dev);
+      if (gd.cfg) launch_nchw_to_nhwc_f32(h->st, xt_d, xd + (size_t)Bd * HW * cpad, Bd, C, HW, cpad, 1.f, 0.f, u->x3 ? 1 : 0, h->overflow_dev);
+    }
+    UNetIO io;
+    io.xin = (const bf16_t*)xin; io.B = Bn; io.tab = tab_d; io.step = k; io.t_shared = true;  // rows k of both tables carry the same t
+    io.dup_tail = dup_tail;
+    io.out = eh; io.out_ld = out_ld;
+    u->forward(c, io);
+    const int is_last = (last_uses_x0 && k == 0) ? 1 : 0;
+    const float* nz = (noise && !is_last) ? noise + (int64_t)(1 + i) * n : nullptr;
+    float* zslot = z_out + (1 + i) * chw;
+    launch_encode_step(h->st, sched_kind, x0, xt_e, eh_e, nz, seed, (uint32_t)(1 + i), zslot, zbs, B, C, HW, tab_e, nullptr, k,
+                       is_last, xin_e, cpad, ge.cfg ? 1 : 0);
+    launch_decode_step(h->st, sched_kind, xt_d, eh_d, zslot, zbs, nullptr, seed, (uint32_t)(0x1000 + i), Bd, C, HW, tab_d,
+                       nullptr, k, xin_d, cpad, gd.cfg ? 1 : 0, nullptr, /*eps_bmod=*/n_dec > 1 ? B : 0);
+    h->pacer.tick(h->st);
+  }
+  HIP_CHECK(hipMemcpyAsync(x_out, xt_d, (size_t)Bd * chw * 4, hipMemcpyDeviceToDevice, h->st));
+  CD_API_END
+}
+
 int cd_pix_refine(cd_handle h, int net, int sched_kind, float* x, int B, int R, const cd_step_coef* coef_host,
                   const float* noise, uint64_t seed) {
   CD_API_BEGIN

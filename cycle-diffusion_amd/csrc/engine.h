@@ -216,6 +216,10 @@ struct UNetIO {
   // B/2 .. B-1 of xin repeat rows 0 .. B/2-1 and only the cross-attention context differs, so everything ahead of the
   // first cross-attention may be computed once for B/2 rows and duplicated
   bool cfg_dup = false;
+  // generalisation for the coupled encode / decode loop (cd_cycle_translate): the batch is [rows 0 .. B - dup_tail - 1 unique |
+  // dup_tail rows that repeat the dup_tail rows just ahead of them], e.g. [encoder rows | decoder uncond | decoder cond]
+  // with dup_tail = the decoder's sample count. cfg_dup is the case dup_tail = B / 2. 0 = no repeated rows.
+  int dup_tail = 0;
   float* out = nullptr;               // fp32 [B*H*W][out_ld]
   int out_ld = 0;
 };

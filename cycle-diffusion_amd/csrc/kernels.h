@@ -39,7 +39,9 @@ void launch_encode_step(hipStream_t st, int kind, const float* x0, float* xt, co
 void launch_decode_step(hipStream_t st, int kind, float* x, const EpsHat& eh, const float* eps,
                         int64_t eps_bstride, const float* noise, uint64_t seed, uint32_t stream,
                         int B, int C, int HW, const StepCoef* tab, const int* step_ptr, int step,
-                        bf16_t* xin, int xin_cpad, int cfg_dup_next, float* x0_pred);
+                        bf16_t* xin, int xin_cpad, int cfg_dup_next, float* x0_pred, int eps_bmod = 0);
+// eps_bmod > 0: sample b takes its injected eps from slot sample b % eps_bmod (the coupled loop decodes several guidance scales
+// of the same eps_bmod encoder samples in one batch)
 void launch_set_int(hipStream_t st, int* p, int v);
 void launch_add_int(hipStream_t st, int* p, int d);
 

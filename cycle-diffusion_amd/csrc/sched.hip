@@ -139,7 +139,7 @@ __global__ void k_decode_step_ddim(float* __restrict__ x, const float* __restric
                                    const float* __restrict__ noise, uint64_t seed,
                                    uint32_t stream, int B, int C, int HW, const StepCoef* tab,
                                    const int* step_ptr, int step_imm, bf16_t* xin, int xin_cpad,
-                                   int cfg_dup_next, float* __restrict__ x0_pred) {
+                                   int cfg_dup_next, float* __restrict__ x0_pred, int eps_bmod) {
   int64_t n = (int64_t)B * C * HW;
   const StepCoef co = pick(tab, step_ptr, step_imm);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
@@ -152,7 +152,7 @@ __global__ void k_decode_step_ddim(float* __restrict__ x, const float* __restric
     float px0 = (xv - co.r * e) / co.sa;
     float dir = co.dirc * e;
     float nz;
-    if (eps) nz = eps[(int64_t)b * eps_bstride + rem];
+    if (eps) nz = eps[(int64_t)(eps_bmod ? b % eps_bmod : b) * eps_bstride + rem];
     else nz = noise ? noise[i] : philox_normal(seed, stream, (uint64_t)i);
     float nn = co.sigma * nz;
     float xn = co.sap * px0 + dir + nn;
@@ -198,7 +198,7 @@ __global__ void k_decode_step_ddpm(float* __restrict__ x, const float* __restric
                                    const float* __restrict__ noise, uint64_t seed,
                                    uint32_t stream, int B, int C, int HW, const StepCoef* tab,
                                    const int* step_ptr, int step_imm, bf16_t* xin,
-                                   int xin_cpad) {
+                                   int xin_cpad, int eps_bmod) {
   int64_t n = (int64_t)B * C * HW;
   const StepCoef co = pick(tab, step_ptr, step_imm);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
@@ -210,7 +210,7 @@ __global__ void k_decode_step_ddpm(float* __restrict__ x, const float* __restric
     float e = eh[(int64_t)b * eh_sb + (int64_t)c * eh_sc + (int64_t)p * eh_sp];
     float mean_p = co.r * (xv - co.dirc * e);
     float nz;
-    if (eps) nz = eps[(int64_t)b * eps_bstride + rem];
+    if (eps) nz = eps[(int64_t)(eps_bmod ? b % eps_bmod : b) * eps_bstride + rem];
     else nz = noise ? noise[i] : philox_normal(seed, stream, (uint64_t)i);
     float xn = mean_p + co.t_mask * co.sigma * nz;
     x[i] = xn;
@@ -255,16 +255,16 @@ void launch_encode_step(hipStream_t st, int kind, const float* x0, float* xt, co
 void launch_decode_step(hipStream_t st, int kind, float* x, const EpsHat& eh, const float* eps,
                         int64_t eps_bstride, const float* noise, uint64_t seed, uint32_t stream,
                         int B, int C, int HW, const StepCoef* tab, const int* step_ptr, int step,
-                        bf16_t* xin, int xin_cpad, int cfg_dup_next, float* x0_pred) {
+                        bf16_t* xin, int xin_cpad, int cfg_dup_next, float* x0_pred, int eps_bmod) {
   int64_t n = (int64_t)B * C * HW;
   if (kind == SCHED_DDIM) {
     hipLaunchKernelGGL(k_decode_step_ddim, dim3(ew_grid(n)), dim3(256), 0, st, x, eh.p, eh.sb,
                        eh.sc, eh.sp, eh.cfg, eh.g, eh.gvec, eps, eps_bstride, noise, seed, stream, B, C, HW,
-                       tab, step_ptr, step, xin, xin_cpad, cfg_dup_next, x0_pred);
+                       tab, step_ptr, step, xin, xin_cpad, cfg_dup_next, x0_pred, eps_bmod);
   } else {
     hipLaunchKernelGGL(k_decode_step_ddpm, dim3(ew_grid(n)), dim3(256), 0, st, x, eh.p, eh.sb,
                        eh.sc, eh.sp, eps, eps_bstride, noise, seed, stream, B, C, HW, tab,
-                       step_ptr, step, xin, xin_cpad);
+                       step_ptr, step, xin, xin_cpad, eps_bmod);
   }
 }
 

@@ -83,9 +83,10 @@ class UNetOpenAI : public UNet {
   void refresh_ln_folds(Ctx& c);
   Act run_block(Ctx& c, const Block& b, Act h, const Act* skip, const float* proj, int proj_ld, bool t_shared);
   Act res_fwd(Ctx& c, const ResW& r, const Act& x, const Act* x2, const float* proj, int proj_ld, bool t_shared);
-  // dup: x holds HALF of a classifier-free-guidance batch (UNetIO::cfg_dup); everything ahead of the cross-attention runs
-  // on it, then the token stream and the block input are duplicated and the rest runs on 2 * x.B rows
-  Act st_fwd(Ctx& c, STW& s, const Act& x, bool dup = false);
+  // dup_tail > 0: x holds the UNIQUE rows of a batch whose last dup_tail samples repeat the dup_tail samples ahead of them
+  // (UNetIO::dup_tail; a classifier-free-guidance batch is dup_tail = x.B); everything ahead of the cross-attention runs on
+  // x, then the token stream and the block input get the repeated samples appended and the rest runs on x.B + dup_tail
+  Act st_fwd(Ctx& c, STW& s, const Act& x, int dup_tail = 0);
   Act ab_fwd(Ctx& c, const ABW& a, const Act& x);
  public:
   ~UNetOpenAI() override { for (void* p : ctx_allocs_) (void)hipFree(p); }
@@ -397,24 +398,27 @@ void UNetOpenAI::set_context(Ctx& c, const bf16_t* ctx, int B, int L) {
   c.f32 = keep_f32; c.x3 = keep_x3;
 }
 
-// rows [0, n) of src -> rows [0, n) and [n, 2n) of dst (dense, `cols` 16-bit elements per row)
-static void dup_rows(Ctx& c, const bf16_t* src, bf16_t* dst, int64_t n, int cols) {
+// rows [0, n) of src -> rows [0, n) of dst, and its last `tail` rows again -> rows [n, n + tail) (dense, `cols` 16-bit
+// elements per row)
+static void dup_rows(Ctx& c, const bf16_t* src, bf16_t* dst, int64_t n, int64_t tail, int cols) {
   launch_copy_strided_bf16(c.st, src, cols, dst, cols, n, cols);
-  launch_copy_strided_bf16(c.st, src, cols, dst + n * cols, cols, n, cols);
+  launch_copy_strided_bf16(c.st, src + (n - tail) * cols, cols, dst + n * cols, cols, tail, cols);
 }
 
-Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x_in, bool dup) {
+Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x_in, int dup_tail) {
   int B = x_in.B;
+  const bool dup = dup_tail > 0;
   const int T = x_in.H * x_in.W, C = s.C;
-  Act out = alloc_act(c, dup ? 2 * B : B, x_in.H, x_in.W, C, /*with_stats=*/true);
+  CD_CHECK(dup_tail >= 0 && dup_tail <= B, "transformer block: %d repeated samples of %d", dup_tail, B);
+  Act out = alloc_act(c, B + dup_tail, x_in.H, x_in.W, C, /*with_stats=*/true);
   Act x = x_in;
   if (dup) {  // the block input at full batch: residual of proj_out (lives as long as the block's output)
     CD_CHECK(x_in.ld == C, "transformer block: dense input expected");
-    x = alloc_act(c, 2 * B, x_in.H, x_in.W, C);
-    dup_rows(c, x_in.p, x.p, (int64_t)B * T, C);
+    x = alloc_act(c, B + dup_tail, x_in.H, x_in.W, C);
+    dup_rows(c, x_in.p, x.p, (int64_t)B * T, (int64_t)dup_tail * T, C);
   }
   const size_t mk = c.arena->mark();
-  CD_CHECK(s.k2c && ctx_B_ == (dup ? 2 * B : B), "cross-attention context not set for batch %d", dup ? 2 * B : B);
+  CD_CHECK(s.k2c && ctx_B_ == B + dup_tail, "cross-attention context not set for batch %d", B + dup_tail);
   ConvOpts p0; p0.pad = 0;
   Act n = groupnorm_fwd(c, s.norm, x_in, nullptr, false);
   Act h = conv_fwd(c, *s.proj_in, n, nullptr, p0);  // tokens [B*T][C]
@@ -508,11 +512,11 @@ Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x_in, bool dup) {
     conv_fwd(c, *s.o1, a, nullptr, o);  // each element is read then written by the same lane
     c.arena->release(m2);
   }
-  if (dup) {  // from here on the two halves see different contexts
-    Act h2 = alloc_act(c, 2 * B, x_in.H, x_in.W, C);
-    dup_rows(c, h.p, h2.p, (int64_t)B * T, C);
+  if (dup) {  // from here on the repeated samples see their own contexts
+    Act h2 = alloc_act(c, B + dup_tail, x_in.H, x_in.W, C);
+    dup_rows(c, h.p, h2.p, (int64_t)B * T, (int64_t)dup_tail * T, C);
     h = h2;
-    B *= 2;
+    B += dup_tail;
   }
   {  // cross-attention over the cached context K / V
     const size_t m2 = c.arena->mark();
@@ -646,26 +650,29 @@ void UNetOpenAI::forward(Ctx& c, const UNetIO& io) {
   // to its self-attention output see identical rows in both halves (the context enters at the cross-attention): they run
   // once on B / 2 rows (CYCLEDIFF_CFG_SHARE=0 turns this off for A/B runs). Per-row arithmetic is unchanged.
   static const bool cfg_share = [] { const char* e = getenv("CYCLEDIFF_CFG_SHARE"); return !(e && e[0] == '0'); }();
-  if (io.cfg_dup && cfg_share && !f32 && io.t_shared && B % 2 == 0 && in_blocks_.size() >= 2 &&
+  CD_CHECK(!(io.cfg_dup && io.dup_tail) && io.dup_tail >= 0 && 2 * io.dup_tail <= B, "U-Net: repeated-row description");
+  const int dtail = io.cfg_dup ? (B % 2 == 0 ? B / 2 : 0) : io.dup_tail;  // trailing samples that repeat the ones ahead of them
+  if (dtail > 0 && cfg_share && !f32 && io.t_shared && in_blocks_.size() >= 2 &&
       in_blocks_[0].layers.size() == 1 && in_blocks_[0].layers[0].kind == Layer::CONV_IN &&
       in_blocks_[1].layers.size() == 2 && in_blocks_[1].layers[0].kind == Layer::RES &&
       in_blocks_[1].layers[1].kind == Layer::ST) {
-    const int Bh = B / 2;
+    const int Bh = B - dtail;  // unique samples
     Act xh = x; xh.B = Bh;
     Act h0 = run_block(c, in_blocks_[0], xh, nullptr, proj, proj_ld, true);  // [Bh] conv_in output
     // the skip connection of the last output block needs it at full batch (with its GroupNorm statistics)
     Act h0f = alloc_act(c, B, h0.H, h0.W, h0.C, /*with_stats=*/h0.stats != nullptr);
     CD_CHECK(h0.ld == h0.C, "conv_in output: dense tensor expected");
-    dup_rows(c, h0.p, h0f.p, h0.rows(), h0.C);
-    if (h0.stats) {
-      dup_rows(c, (const bf16_t*)h0.stats, (bf16_t*)h0f.stats_buf, (h0.rows() / 32) * 2, h0.C * 2);  // fp32 as 2 x 16 bit
+    const int64_t rows_tail = (int64_t)dtail * h0.H * h0.W;
+    dup_rows(c, h0.p, h0f.p, h0.rows(), rows_tail, h0.C);
+    if (h0.stats) {  // [row block][2][C] fp32 (a 32-row block lies inside one sample), copied as 2 x 16 bit
+      dup_rows(c, (const bf16_t*)h0.stats, (bf16_t*)h0f.stats_buf, (h0.rows() / 32) * 2, (rows_tail / 32) * 2, h0.C * 2);
       h0f.stats = h0f.stats_buf;
     }
     hs.push_back(h0f);
     const Layer& lr = in_blocks_[1].layers[0];
     const Layer& lt = in_blocks_[1].layers[1];
     Act hr = res_fwd(c, res_[lr.idx], h0, nullptr, proj, proj_ld, true);
-    h = st_fwd(c, st_[lt.idx], hr, /*dup=*/true);
+    h = st_fwd(c, st_[lt.idx], hr, /*dup_tail=*/dtail);
     hs.push_back(h);
     first_full = 2;
   }

@@ -340,6 +340,38 @@ class Engine:
             self._keep = g  # the launches read it asynchronously
         return x
 
+    def cycle_translate(self, net, kind, x0, coef_enc, coef_dec, enc_ctx_c=None, enc_ctx_uc=None, enc_guidance=1.0,
+                        dec_ctx_c=None, dec_ctx_uc=None, dec_guidance=1.0, n_dec=1, noise=None, seed=0, last_uses_x0=True):
+        """The coupled loop (cd_cycle_translate): dpm_encode and ddim_decode of the same network over the whole chain with ONE
+        forward per step over [encoder rows | decoder rows]. x0 [B, C, H, W]; dec_ctx_* [n_dec * B, L, Dc] (decoder row
+        j * B + b decodes encoder sample b); dec_guidance one scale or n_dec * B of them (none 0 or 1).
+        Returns (z [B, K+1, C, H, W], x [n_dec * B, C, H, W])."""
+        x0 = self._f32(x0)
+        K = len(coef_dec)
+        assert len(coef_enc) == K + 1
+        B, Cc, H, W = x0.shape
+        z = torch.empty((B, K + 1, Cc, H, W), device=x0.device, dtype=torch.float32)
+        x = torch.empty((n_dec * B, Cc, H, W), device=x0.device, dtype=torch.float32)
+        coef_enc, coef_dec = np.ascontiguousarray(coef_enc), np.ascontiguousarray(coef_dec)
+        ctxs = [self._f32(t) if t is not None else None for t in (enc_ctx_c, enc_ctx_uc, dec_ctx_c, dec_ctx_uc)]
+        L = next((t.shape[1] for t in ctxs if t is not None), 0)
+        for t, rows in zip(ctxs, (B, B, n_dec * B, n_dec * B)):
+            assert t is None or t.shape[0] == rows, (t.shape, rows)
+        gvec, gscalar = None, 1.0
+        if isinstance(dec_guidance, (int, float)):
+            gscalar = float(dec_guidance)
+        else:
+            gvec = torch.as_tensor(dec_guidance, dtype=torch.float32).to(x0.device).contiguous()
+            if gvec.numel() != n_dec * B or bool(((gvec == 0) | (gvec == 1)).any()):
+                raise ValueError("per-sample guidance: n_dec * B scales, none of them 0 or 1")
+        nz = self._f32(noise) if noise is not None else None
+        check(self.lib.cd_cycle_translate(self.h, net, kind, ptr(x0), ptr(ctxs[0]), ptr(ctxs[1]), C.c_float(enc_guidance),
+                                          ptr(ctxs[2]), ptr(ctxs[3]), C.c_float(gscalar), ptr(gvec), L, B, n_dec, K,
+                                          C.c_void_p(coef_enc.ctypes.data), C.c_void_p(coef_dec.ctypes.data), ptr(nz),
+                                          C.c_uint64(seed), int(last_uses_x0), ptr(z), ptr(x)))
+        self._keep = (gvec, ctxs, nz)  # the launches read them asynchronously
+        return z, x
+
     def pix_refine(self, net, kind, x, coef, noise=None, seed=0):
         x = self._f32(x).clone()
         R = len(coef) - 1

@@ -65,7 +65,7 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
     def __init__(self, source_model_type, custom_steps, eta, white_box_steps, skip_steps,
                  encoder_unconditional_guidance_scales=None, decoder_unconditional_guidance_scales=None,
                  n_trials=None, cond_stage=None, ranker=None, device=None, text_encoder=None,
-                 noise_on_cpu=False, fold_ensemble=True, ranker_path=None, precision="fp16"):
+                 noise_on_cpu=False, fold_ensemble=True, ranker_path=None, precision="fp16", couple=True):
         super().__init__()
         # `[gan] precision`: arithmetic of the U-Net AND (round 5) of the first stage - the reference's `precision = "full"` covers
         # both (sd_wrapper:117, autoencoder.py:324-333); the text towers stay 16-bit (their output is the conditioning, rounded
@@ -88,6 +88,8 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
         # parity runs draw every noise tensor on the CPU in the reference's order; throughput
         # runs draw on the device
         self.noise_on_cpu, self.fold_ensemble = bool(noise_on_cpu), bool(fold_ensemble)
+        # `[gan] couple = False`: translate() runs encode() then forward() as two loops (the reference's own order of work)
+        self.couple = bool(couple) and os.environ.get("CYCLEDIFF_COUPLE", "1") != "0"
         self.noise_source = None
         self.engine = get_engine(device)
         udesc = self.UNET_DESC()
@@ -190,7 +192,8 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
         return [groups[k] for k in order]
 
     # ---- encode (sd_wrapper:169-206)
-    def encode(self, image, encode_text):
+    def _encode_front(self, image, encode_text):
+        """first stage, conditioning and the members' noise in the reference's draw order -> (x0, c, uc, members)"""
         image = (image - 0.5) * 2.0
         assert image.shape[2] == image.shape[3] == self.resolution
         image = image.to(self.device, torch.float32)
@@ -224,6 +227,11 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
                     else:
                         nz = self._randn((n_draw,) + tuple(x0.shape))
                     members.append((float(enc_scale), int(skip), nz))
+        return x0, c, uc, members
+
+    def encode(self, image, encode_text):
+        x0, c, uc, members = self._encode_front(image, encode_text)
+        bsz, sch = x0.shape[0], self._schedule()
         z_ensemble = [None] * len(members)
         per_call = max(1, self.MAX_FOLD // bsz)
         for grp in self._groups([(m[0], m[1]) for m in members]):
@@ -248,11 +256,13 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
         return max(0, min(K, self.white_box_steps - skip - 1))
 
     # ---- generate (sd_wrapper:142-167)
-    def generate(self, z_ensemble, decode_text):
+    def generate(self, z_ensemble, decode_text, latents=None):
+        """`latents` (translate()): {output slot: latent [bsz, C, h, w]} of candidates the coupled loop already decoded."""
         sch = self._schedule()
         n_dec = len(self.decoder_unconditional_guidance_scales)
         bsz = z_ensemble[0].shape[0]
         c, uc = self.get_condition(decode_text, bsz)
+        latents = dict(latents or {})
         jobs = []  # (output slot, skip, decoder scale, z) in the reference's order: z member -> decoder scale
         for i, z in enumerate(z_ensemble):
             skip = self.skip_steps[i % len(self.skip_steps)]
@@ -270,40 +280,90 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
                     else:
                         tail = self._randn((n_tail,) + shape)
                 jobs.append((i * n_dec + j, int(skip), float(dec_scale), zz, tail))
-        img_ensemble = [None] * len(jobs)
+        n_jobs = len(jobs)
         per_call = max(1, self.MAX_FOLD // bsz)
-
-        def kind(scale):  # which network batch a scale needs (ddim.py:550-559)
-            return "cond" if scale == 1.0 else ("uncond" if scale == 0.0 else "cfg")
+        todo = [jb for jb in jobs if jb[0] not in latents]
 
         # jobs that share the skip and the batch structure fold into one engine call; inside a classifier-free-guidance
         # group every sample carries its own scale (cd_ddim_decode_v), so the 5 guided scales of the reference's config
         # fill the calls instead of running 15 members at a time
-        for grp in self._groups([(jb[1], kind(jb[2]), jb[2] if kind(jb[2]) != "cfg" else None) for jb in jobs]):
-            skip = jobs[grp[0]][1]
+        for grp in self._groups([(jb[1], self._kind(jb[2]), jb[2] if self._kind(jb[2]) != "cfg" else None) for jb in todo]):
+            skip = todo[grp[0]][1]
             for idx in self._chunks(grp, per_call):
                 n = len(idx)
-                scales = [jobs[i][2] for i in idx]
-                if kind(scales[0]) == "cfg" and len(set(scales)) > 1:
+                scales = [todo[i][2] for i in idx]
+                if self._kind(scales[0]) == "cfg" and len(set(scales)) > 1:
                     guidance = torch.tensor([sc for sc in scales for _ in range(bsz)], dtype=torch.float32)
                 else:
                     guidance = scales[0]
                 x = self.engine.ddim_decode(self.unet, _ffi.CD_SCHED_DDIM,
-                                            torch.cat([jobs[i][3] for i in idx], dim=0).contiguous(),
+                                            torch.cat([todo[i][3] for i in idx], dim=0).contiguous(),
                                             sch.coef_decode(skip), ctx_c=c.repeat(n, 1, 1), ctx_uc=uc.repeat(n, 1, 1),
                                             guidance=guidance,
-                                            noise_tail=None if jobs[idx[0]][4] is None else
-                                            torch.cat([jobs[i][4] for i in idx], dim=1).contiguous())
-                # decode_first_stage, then post_process (x+1)/2 fused into the final layout kernel
-                per = self._vae_batch()
-                img = torch.cat([self.engine.vae_decode(self.vae, x[i:i + per].contiguous(), scale=self.SCALE_FACTOR,
-                                                        out_mul=0.5, out_add=0.5) for i in range(0, x.shape[0], per)], 0)
+                                            noise_tail=None if todo[idx[0]][4] is None else
+                                            torch.cat([todo[i][4] for i in idx], dim=1).contiguous())
                 for j, i in enumerate(idx):
-                    img_ensemble[jobs[i][0]] = img[j * bsz:(j + 1) * bsz]
-        return img_ensemble
+                    latents[todo[i][0]] = x[j * bsz:(j + 1) * bsz]
+        # decode_first_stage, then post_process (x+1)/2 fused into the final layout kernel; candidates in output order, in calls
+        # of at most _vae_batch() images
+        per = self._vae_batch()
+        lat = torch.cat([latents[k] for k in range(n_jobs)], 0)
+        img = torch.cat([self.engine.vae_decode(self.vae, lat[i:i + per].contiguous(), scale=self.SCALE_FACTOR,
+                                                out_mul=0.5, out_add=0.5) for i in range(0, lat.shape[0], per)], 0)
+        return [img[k * bsz:(k + 1) * bsz] for k in range(n_jobs)]
+
+    @staticmethod
+    def _kind(scale):  # which network batch a scale needs (ddim.py:550-559)
+        return "cond" if scale == 1.0 else ("uncond" if scale == 0.0 else "cfg")
+
+    # ---- encode + generate as ONE coupled loop (north_star; include/cyclediff.h cd_cycle_translate)
+    def translate(self, image, encode_text, decode_text):
+        """What Model.forward composes (model/text_unsupervised_translation.py:24-40): `self(encode(image, encode_text), image,
+        encode_text, decode_text)`, with the DPM-Encoder and the decode of every ensemble member running as one loop - step k of
+        both evaluates the same U-Net at the same timestep, and the decode step needs eps_k only after its forward, so each
+        step is ONE forward over [encoder rows | decoder rows] (C2: 12 rows per step for a batch of 4 instead of 4, then 8).
+        Same draws in the same order, same member order, same per-sample arithmetic as the two calls. Chains that leave part
+        of the decode to fresh noise (white_box_steps shorter than the chain) take the two calls."""
+        sch = self._schedule()
+        whole = all(self._white_box_loop(len(sch) - sk, sk) == len(sch) - sk for sk in self.skip_steps)
+        if not (self.couple and whole):
+            z_ensemble = self.encode(image, encode_text)
+            return self.forward(z_ensemble, image, encode_text, decode_text)
+        x0, c_src, uc, members = self._encode_front(image, encode_text)
+        bsz = x0.shape[0]
+        c_tgt, _ = self.get_condition(decode_text, bsz)
+        dec_scales = [float(sc) for sc in self.decoder_unconditional_guidance_scales]
+        n_dec = len(dec_scales)
+        kinds = [self._kind(sc) for sc in dec_scales]
+        main = "cfg" if "cfg" in kinds else kinds[0]  # the decoder scales that ride with the encoder (the others decode from z)
+        ride = [j for j in range(n_dec) if kinds[j] == main and (main == "cfg" or dec_scales[j] == dec_scales[kinds.index(main)])]
+        z_ensemble, latents = [None] * len(members), {}
+        per_call = max(1, self.MAX_FOLD // (bsz * (1 + len(ride))))
+        for grp in self._groups([(m[0], m[1]) for m in members]):
+            enc_scale, skip = members[grp[0]][0], members[grp[0]][1]
+            for idx in self._chunks(grp, per_call):
+                n, nr = len(idx), len(ride)
+                if main == "cfg" and len({dec_scales[j] for j in ride}) > 1:
+                    guidance = torch.tensor([dec_scales[j] for j in ride for _ in range(n * bsz)], dtype=torch.float32)
+                else:
+                    guidance = dec_scales[ride[0]]
+                z, x = self.engine.cycle_translate(
+                    self.unet, _ffi.CD_SCHED_DDIM, x0.repeat(n, 1, 1, 1), sch.coef_encode(skip), sch.coef_decode(skip),
+                    enc_ctx_c=c_src.repeat(n, 1, 1), enc_ctx_uc=uc.repeat(n, 1, 1), enc_guidance=enc_scale,
+                    dec_ctx_c=c_tgt.repeat(n * nr, 1, 1), dec_ctx_uc=uc.repeat(n * nr, 1, 1), dec_guidance=guidance, n_dec=nr,
+                    noise=torch.cat([members[i][2] for i in idx], dim=1), last_uses_x0=True)
+                for m, i in enumerate(idx):
+                    z_ensemble[i] = z[m * bsz:(m + 1) * bsz].reshape(bsz, -1)
+                    for jr, j in enumerate(ride):  # decoder row (jr * n + m) * bsz + b
+                        latents[i * n_dec + j] = x[(jr * n + m) * bsz:(jr * n + m + 1) * bsz]
+        img_ensemble = self.generate(z_ensemble, decode_text, latents=latents)
+        return self._select(img_ensemble, image, encode_text, decode_text)
 
     def forward(self, z_ensemble, original_img, encode_text, decode_text):
-        img_ensemble = self.generate(z_ensemble, decode_text)
+        return self._select(self.generate(z_ensemble, decode_text), original_img, encode_text, decode_text)
+
+    def _select(self, img_ensemble, original_img, encode_text, decode_text):
+        """the candidate the reference returns (sd_wrapper:213-249): the only one, or per sample the directional-CLIP argmax"""
         assert len(img_ensemble) == len(self.decoder_unconditional_guidance_scales) * \
             len(self.encoder_unconditional_guidance_scales) * len(self.skip_steps) * self.n_trials
         if len(img_ensemble) == 1:

@@ -15,9 +15,14 @@ class TextUnsupervisedTranslation(nn.Module):
     def forward(self, sample_id, original_image, encode_text, decode_text):
         self.gan_wrapper.eval()
         assert not self.training
-        z_ensemble = self.gan_wrapper.encode(image=original_image, encode_text=encode_text)
-        img = self.gan_wrapper(z_ensemble=z_ensemble, original_img=original_image, encode_text=encode_text,
-                               decode_text=decode_text)
+        if hasattr(self.gan_wrapper, "translate"):
+            # encode() + forward() as the engine's coupled loop: ONE U-Net forward per step over [encoder rows | decoder
+            # rows] (include/cyclediff.h cd_cycle_translate); same draws, member order and per-sample arithmetic
+            img = self.gan_wrapper.translate(original_image, encode_text, decode_text)
+        else:
+            z_ensemble = self.gan_wrapper.encode(image=original_image, encode_text=encode_text)
+            img = self.gan_wrapper(z_ensemble=z_ensemble, original_img=original_image, encode_text=encode_text,
+                                   decode_text=decode_text)
         return (original_image, img), torch.zeros_like(sample_id).float(), dict()
 
     @property

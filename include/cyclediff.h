@@ -181,6 +181,24 @@ int cd_ddim_decode_v(cd_handle h, int net, int sched_kind, const float* z, int z
                      const float* ctx_c, const float* ctx_uc, int ctx_len, const float* guidance_per_sample, int B,
                      int K, const cd_step_coef* coef_host, const float* noise_tail, uint64_t seed, float* x_out);
 
+/* The coupled source -> target loop in ONE call: what Model.forward composes from the wrapper's encode() and forward()
+ * (model/text_unsupervised_translation.py:24-40: z = gan_wrapper.encode(image, encode_text); img = gan_wrapper(z, ...)) when
+ * both run on the same network over the whole chain (white_box_steps = custom_steps + 1): the DPM-Encoder step and the decode
+ * step of index k evaluate the network at the same timestep, and the decode step needs eps_k only after its forward, so each
+ * of the K iterations runs ONE forward over [encoder rows | decoder rows], then the encoder's step kernel (ddim.py:582-601,
+ * 545-580) and the decoder's (ddim.py:603-646), which reads the eps the encoder just wrote.
+ *   x0 [B,C,H,W]; enc_ctx_* [B,L,Dc] and enc_guidance as cd_dpm_encode's; the decoder runs n_dec decodes per encoder sample
+ *   (the wrapper's decoder_unconditional_guidance_scales of one kind, sd_wrapper:155-166): dec_ctx_* [n_dec*B,L,Dc], decoder
+ *   row j*B + b decodes the z of encoder sample b; dec_guidance (scalar) or dec_guidance_per_sample (device, n_dec*B floats,
+ *   each neither 0 nor 1) as cd_ddim_decode / cd_ddim_decode_v; coef_enc_host K+1 rows, coef_dec_host K rows (the same rows
+ *   0..K-1); noise [K,B,C,H,W] or NULL and last_uses_x0 as cd_dpm_encode's.
+ *   z_out [B,K+1,C,H,W] (what encode() returns), x_out [n_dec*B,C,H,W] (what the decode returns). */
+int cd_cycle_translate(cd_handle h, int net, int sched_kind, const float* x0, const float* enc_ctx_c,
+                       const float* enc_ctx_uc, float enc_guidance, const float* dec_ctx_c, const float* dec_ctx_uc,
+                       float dec_guidance, const float* dec_guidance_per_sample, int ctx_len, int B, int n_dec, int K,
+                       const cd_step_coef* coef_enc_host, const cd_step_coef* coef_dec_host, const float* noise,
+                       uint64_t seed, int last_uses_x0, float* z_out, float* x_out);
+
 /* Stochastic refinement (ddpm_ddim_wrapper.py:431-453): x_t = sa*x + s1a*n (row R of coef_host),
  * then R random-noise steps rows R-1..0. noise [R+1,B,C,H,W] or NULL. In/out x [B,C,H,W]. */
 int cd_pix_refine(cd_handle h, int net, int sched_kind, float* x, int B, int R,

@@ -91,7 +91,8 @@ def pytest_sessionfinish(session, exitstatus):
     out = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "parity_report.json"), "w") as f:
+        # CYCLEDIFF_PARITY_REPORT: a child session (the bf16-library test runs pytest in a subprocess) keeps its own file
+        with open(os.path.join(out, os.environ.get("CYCLEDIFF_PARITY_REPORT") or "parity_report.json"), "w") as f:
             json.dump(_REPORT.rows, f, indent=1)
     except OSError:
         pass

@@ -43,3 +43,26 @@ def test_world_size_mismatch_is_an_error_not_a_hang():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "1"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "does not match --gpus" in r.stderr
+
+
+def _cores():
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def test_eight_ranks_dry_run_c4_and_c5_batches():
+    """BASELINE configs 4 and 5 name 8 GPUs: SD-v1.4 batch 64 (8 per GPU) and AFHQ batch 32 (4 per GPU). The 8-GPU node is the
+    driver's; here the same launch path runs 8 gloo ranks on the host: every rank's id arrives through one all-gather
+    (`ranks_seen`), every step gathers one full global batch, and each rank caps its host threads at cores // 8."""
+    res = _run(["--gpus", "8", "--steps", "3", "--warmup", "0", "--coalesce", "2", "--batch", "8", "--dry-run"])
+    assert res["n_gpus"] == 8 and res["ranks_seen"] == list(range(8))
+    assert res["config"]["parallelism"] == "dp8" and res["config"]["global_batch"] == 64 and res["config"]["batch_per_gpu"] == 8
+    assert res["host_threads_per_rank"] == max(1, _cores() // 8)
+    res = _run(["--gpus", "8", "--workload", "c5", "--steps", "2", "--warmup", "0", "--dry-run"])
+    assert res["ranks_seen"] == list(range(8)) and res["config"]["global_batch"] == 32 and res["config"]["batch_per_gpu"] == 4

@@ -135,6 +135,33 @@ def test_c2_sd_v14_512_end_to_end_vs_reference(report):
     _run(SDStochasticTextWrapper, "c2_sd512_e2e", 512, 768, report)
 
 
+def test_c2_sd_v14_512_end_to_end_on_the_bf16_library(report):
+    """BASELINE.json's C2 line says bf16; the product stores fp16 (same width and MFMA rate, 8x less round-off into the
+    DPM-Encoder's 1 / sigma amplification: DESIGN.md 6). The bf16 build of the same sources (lib/libcyclediff_bf16.so, made by
+    __graft_entry__.build()) runs the same fixture at ITS stated floor - 34 dB, measured 36-38 dB over rounds 3-5 - in a child
+    pytest session whose library is selected with CYCLEDIFF_LIB (one process loads one library)."""
+    import subprocess
+    import sys
+    from cycle_diffusion_amd import _ffi as ffi
+    lib = os.path.join(os.path.dirname(ffi.LIB_PATH), "libcyclediff_bf16.so")
+    assert os.path.exists(lib), "the bf16 library is missing: run __graft_entry__.build()"
+    if os.environ.get("CYCLEDIFF_LIB"):
+        pytest.skip("already a child session on a selected library")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name = "parity_report_bf16_library.json"
+    env = dict(os.environ, CYCLEDIFF_LIB=lib, CYCLEDIFF_PARITY_REPORT=name, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "test_c2_sd_v14_512_end_to_end_vs_reference"], env=env, cwd=root, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "1 passed" in r.stdout, r.stdout[-2000:]
+    rows = json.load(open(os.path.join(root, "gpurun_out", name)))
+    row = [x for x in rows if x["name"] == "e2e/c2_sd512_e2e"][0]
+    report.add("e2e/c2_sd512_e2e_bf16_library", psnr_db=row["psnr_db"], cycle99_rms=row["cycle99_rms"],
+               eps_rel_slots=row["eps_rel_slots"], floor_db=34.0)
+    assert 34.0 <= row["psnr_db"] < 50.0, row["psnr_db"]  # the bf16 build really ran (the fp16 build gives 55 dB)
+
+
 def test_c3_ldm_text2img_256_end_to_end_vs_reference(report):
     """BASELINE config 3: LDM text2img-large shapes at 256 x 256 through LatentDiffStochasticTextWrapper
     (latentdiff_stochastic_text_wrapper.py:168-201; posterior mean)."""

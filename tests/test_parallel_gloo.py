@@ -169,3 +169,22 @@ def test_in_flight_rounds_keep_collectives_in_step_order_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def test_shard_sampler_at_world_8_with_wrap_around_padding():
+    """ShardSampler semantics (trainer/trainer.py:288-293) at the rank counts BASELINE configs 4 / 5 name: 8 ranks x batch 8
+    (C4) and 8 x 4 (C5) on datasets that do not fill the last global batch - every rank gets the same number of full batches,
+    the padding wraps around to the first samples, every real sample appears exactly once among the non-padding slots."""
+    from cycle_diffusion_amd.parallel import global_order, shard_indices, shard_padding
+    for n, bs in ((150, 8), (100, 4), (64, 8), (5, 4), (33, 4)):
+        world, gb = 8, bs * 8
+        total = -(-n // gb) * gb
+        per_rank = [shard_indices(n, bs, world, r) for r in range(world)]
+        pads = [shard_padding(n, bs, world, r) for r in range(world)]
+        assert len({len(p) for p in per_rank}) == 1 and all(len(b) == bs for p in per_rank for b in p)
+        order = global_order(n, bs, world)
+        assert len(order) == total and order[:n] == list(range(n))
+        assert order[n:] == [i % n for i in range(total - n)]  # wrap-around, as `indices += indices[:pad]` repeated
+        real = [i for r in range(world) for b, pd in zip(per_rank[r], pads[r]) for i, is_pad in zip(b, pd) if not is_pad]
+        assert sorted(real) == list(range(n))
+        assert sum(is_pad for r in range(world) for pd in pads[r] for is_pad in pd) == total - n
