@@ -602,7 +602,8 @@ def main():
 
     # BASELINE's literal operating point beside the folded one: launch sets of ONE step (a batch of B triplets per
     # engine call, B' = B through the DPM-Encoder), timed the same way on every rank
-    single_dt = None
+    single_dt, single_coupled = None, None
+    timed_coupled = getattr(wrapper, "last_translate_coupled", None)  # of the timed launch sets
     if single:
         gather(0, compute(0, 1))
         sync()
@@ -611,6 +612,7 @@ def main():
             gather(0, compute(0, 1))
         sync()
         single_dt = time.perf_counter() - t1
+        single_coupled = getattr(wrapper, "last_translate_coupled", None)
         if dist.is_initialized():
             tt = torch.tensor([single_dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -708,6 +710,7 @@ def main():
             sv = a.single_steps * B * world / single_dt
             res["single_batch_value"] = sv  # images/s with ONE batch of B per launch set (`--coalesce 1`)
             res["single_batch"] = {"value": sv, "unit": "images/s", "steps": a.single_steps,
+                                   "coupled_loop": single_coupled,
                                    "ms_per_step": 1e3 * single_dt / a.single_steps, "images_in_flight_per_gpu": B,
                                    "whole_path_frac": sv * wl["flop_per_image"] / 1e12 / (world * peak)}
         if (world == 1 and not a.no_bf16 and a.workload == "c2" and not (f32 or x3) and fmt == "fp16"

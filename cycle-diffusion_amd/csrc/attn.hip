@@ -664,7 +664,13 @@ void launch_attention(hipStream_t st, const AttnParams& p) {
 #endif
     // round 5: the LDS-DMA / 16-row-block form (k_attention_d40); CD_ATTN_D40=0 selects the round-3 kernel for A/B runs
     static const bool d40_new = [] { const char* e = getenv("CD_ATTN_D40"); return !(e && e[0] == '0'); }();
-    if (d40_new && p.vt_dpad >= 40 && (p.ldk % 8) == 0 && (p.vt_tpad % 8) == 0 &&
+    // what the kernel's 16-byte accesses and its ragged last key tile assume (round-5 advisor): V^T rows padded to whole
+    // 64-key tiles (a tighter pad would let the last tile of one d row read the next row's data), q / k / V^T row strides
+    // and base pointers on 16-byte boundaries; anything else takes the round-3 kernel
+    const bool aligned16 = ((((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.vt | (uintptr_t)p.o) & 15) == 0) &&
+                           (p.ldq % 8) == 0 && (p.ldk % 8) == 0 && (p.ldo % 8) == 0 && (p.q_bs % 8) == 0 && (p.k_bs % 8) == 0 &&
+                           (p.o_bs % 8) == 0;
+    if (d40_new && p.vt_dpad >= 40 && aligned16 && (p.vt_tpad % 8) == 0 && p.vt_tpad >= ceil_div(p.Tk, 64) * 64 &&
         (int64_t)p.Tk * p.ldk * 2 < (1ll << 31) && (int64_t)p.vt_dpad * p.vt_tpad * 2 < (1ll << 31))
       hipLaunchKernelGGL((k_attention_d40<8>), dim3(ceil_div(p.Tq, 256), p.H, p.B), dim3(512), 0, st, p);
     else

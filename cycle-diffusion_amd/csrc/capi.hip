@@ -183,7 +183,7 @@ int cd_engine_create(void* hip_stream, size_t workspace_bytes, cd_handle* out) {
   HIP_CHECK(hipMalloc((void**)&h->splitk.flags, h->splitk.nflags * sizeof(int)));
   HIP_CHECK(hipMemset(h->splitk.flags, 0, h->splitk.nflags * sizeof(int)));
   HIP_CHECK(hipDeviceSynchronize());
-  h->gn_partial_floats = (size_t)1 << 20;
+  h->gn_partial_floats = (size_t)1 << 23;  // 32 MB: statistics partials + coefficients of a B = 192 forward (coupled loop, fold 16) need 1.8 M floats
   HIP_CHECK(hipMalloc((void**)&h->gn_partial, h->gn_partial_floats * sizeof(float)));
   h->pacer.init();
   h->coef_staging.init();

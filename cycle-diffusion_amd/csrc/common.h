@@ -80,7 +80,14 @@ __device__ inline void unpack8(const uint4& raw, float* f) {
 #endif
 
 __device__ inline uint32_t pack2(float lo, float hi) {
+#if CD_ACT_FP16 && defined(__HIP_DEVICE_COMPILE__)  // two v_med3_f32 + one v_cvt_pk_f16_f32 (see pack8)
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  const h2 v = {(_Float16)__builtin_amdgcn_fmed3f(lo, -65504.0f, 65504.0f),
+                (_Float16)__builtin_amdgcn_fmed3f(hi, -65504.0f, 65504.0f)};
+  return __builtin_bit_cast(uint32_t, v);
+#else
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+#endif
 }
 // two softmax probabilities, known to lie in [0, 2^8] (deferred-maximum attention): one hardware convert, no
 // saturation needed
@@ -100,11 +107,28 @@ constexpr uint32_t kOnePair = 0x3C003C00u;  // two 16-bit 1.0 values
 #else
 constexpr uint32_t kOnePair = 0x3F803F80u;
 #endif
+// eight fp32 values -> eight 16-bit storage words. fp16 build: one v_med3_f32 per value (the +-65504 saturation of f2bf)
+// and one v_cvt_pk_f16_f32 per pair - 12 VALU operations; the f2bf form compiles to two compare / select pairs, a convert,
+// an SDWA convert and an OR per pair, ~50 operations per vector, and the GEMM epilogues are VALU-issue-bound (round 6:
+// every k_conv_gemm tile spends 13-40 % of its time in its row passes). Same bits as f2bf for every non-NaN input; a NaN
+// saturates instead of passing through.
 __device__ inline uint4 pack8(const float* f) {
+#if CD_ACT_FP16 && defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const h2 v = {(_Float16)__builtin_amdgcn_fmed3f(f[2 * i], -65504.0f, 65504.0f),
+                  (_Float16)__builtin_amdgcn_fmed3f(f[2 * i + 1], -65504.0f, 65504.0f)};
+    w[i] = __builtin_bit_cast(uint32_t, v);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+#else
   uint4 r;
   r.x = pack2(f[0], f[1]); r.y = pack2(f[2], f[3]);
   r.z = pack2(f[4], f[5]); r.w = pack2(f[6], f[7]);
   return r;
+#endif
 }
 
 // Sum over the 64 lanes of a wave, result in every lane, without the LDS crossbar: quad_perm / row_half_mirror /

@@ -920,13 +920,31 @@ int dispatch(hipStream_t st, const ConvGemmParams& p, int id) {
 
 thread_local const char* g_last_cfg = "";
 
+// CU count of the current device (256 on an unpartitioned MI355X; a partitioned part has fewer): "does this configuration
+// fill the chip" is asked against it, not against a literal
+int device_cu_count() {
+  static std::atomic<int> ncu_of[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int n = ncu_of[dev & 63].load(std::memory_order_relaxed);
+  if (!n) {
+    hipDeviceProp_t prop;
+    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    ncu_of[dev & 63].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
+// shapes the tile table does not know (and tuning is off): the largest of three tiles that still fills the chip - "fills" is
+// asked against the device's CU count (256 on an unpartitioned MI355X), not a literal
 int pick_config(const ConvGemmParams& p) {
+  const int64_t ncu = device_cu_count();
   const int64_t t128 = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 128) * p.nbatch;
   const int64_t t12864 = (int64_t)ceil_div(p.M, 128) * ceil_div(p.N, 64) * p.nbatch;
-  if (p.act == ACT_GEGLU) return (t128 >= 384) ? 1 : 2;  // GEGLU needs a wave tile >= 64 columns wide
-  if (t128 >= 384 && p.N % 128 == 0) return 1;
-  if (t128 >= 512) return 1;
-  if (t12864 >= 256) return 2;
+  if (p.act == ACT_GEGLU) return (2 * t128 >= 3 * ncu) ? 1 : 2;  // GEGLU needs a wave tile >= 64 columns wide
+  if (2 * t128 >= 3 * ncu && p.N % 128 == 0) return 1;
+  if (t128 >= 2 * ncu) return 1;
+  if (t12864 >= ncu) return 2;
   return 3;
 }
 
@@ -1031,21 +1049,6 @@ void tune_cache_append(const ShapeKey& k, int val) {
 }
 
 std::mutex g_tune_mu;  // engines on different host threads share one table; tuning itself is serialised
-
-// CU count of the current device (256 on an unpartitioned MI355X; a partitioned part has fewer): "does this configuration
-// fill the chip" is asked against it, not against a literal
-int device_cu_count() {
-  static std::atomic<int> ncu_of[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 256;
-  int n = ncu_of[dev & 63].load(std::memory_order_relaxed);
-  if (!n) {
-    hipDeviceProp_t prop;
-    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    ncu_of[dev & 63].store(n, std::memory_order_relaxed);
-  }
-  return n;
-}
 
 int tuned_config(hipStream_t st, const ConvGemmParams& p, bool k64) {
   std::lock_guard<std::mutex> lock(g_tune_mu);

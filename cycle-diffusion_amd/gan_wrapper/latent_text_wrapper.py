@@ -61,6 +61,7 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
     # level is 64 MiB per image and tensor in 16 bits (256 MiB in fp32), several of them live at once - a look-ahead fold of
     # 64 images through ONE decode would need ~25 GB of workspace for 1.5 % of the path's FLOPs
     VAE_MAX_PIXELS = 32 * 512 * 512
+    COUPLE_MAX_TOKENS = 96 * 64 * 64  # rows x latent tokens of one coupled forward (translate())
 
     def __init__(self, source_model_type, custom_steps, eta, white_box_steps, skip_steps,
                  encoder_unconditional_guidance_scales=None, decoder_unconditional_guidance_scales=None,
@@ -88,8 +89,15 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
         # parity runs draw every noise tensor on the CPU in the reference's order; throughput
         # runs draw on the device
         self.noise_on_cpu, self.fold_ensemble = bool(noise_on_cpu), bool(fold_ensemble)
-        # `[gan] couple = False`: translate() runs encode() then forward() as two loops (the reference's own order of work)
+        # `[gan] couple = False`: translate() runs encode() then forward() as two loops (the reference's own order of work).
+        # The coupled loop is taken while its forward - [encoder rows | decoder rows] x latent tokens - stays below
+        # COUPLE_MAX_TOKENS: measured on MI355X (profiles/r6_coupled_loop_ab.json) it is +28 % at a batch of 4 (12 rows of
+        # 64 x 64 tokens per forward instead of 4, then 8), +7 % on config 3 (192 rows of 32 x 32) and -1.4 % at 64 images of
+        # 512 x 512 (192 rows of 64 x 64: a 503 MB activation per 320-channel tensor no longer stays in the 256 MB Infinity
+        # Cache between producer and consumer, where the two loops run 64 and 128 rows)
         self.couple = bool(couple) and os.environ.get("CYCLEDIFF_COUPLE", "1") != "0"
+        self.couple_max_tokens = int(os.environ.get("CYCLEDIFF_COUPLE_MAX_TOKENS", self.COUPLE_MAX_TOKENS))
+        self.last_translate_coupled = None
         self.noise_source = None
         self.engine = get_engine(device)
         udesc = self.UNET_DESC()
@@ -326,19 +334,22 @@ class _LatentStochasticTextWrapper(torch.nn.Module):
         of the decode to fresh noise (white_box_steps shorter than the chain) take the two calls."""
         sch = self._schedule()
         whole = all(self._white_box_loop(len(sch) - sk, sk) == len(sch) - sk for sk in self.skip_steps)
-        if not (self.couple and whole):
-            z_ensemble = self.encode(image, encode_text)
-            return self.forward(z_ensemble, image, encode_text, decode_text)
-        x0, c_src, uc, members = self._encode_front(image, encode_text)
-        bsz = x0.shape[0]
-        c_tgt, _ = self.get_condition(decode_text, bsz)
         dec_scales = [float(sc) for sc in self.decoder_unconditional_guidance_scales]
         n_dec = len(dec_scales)
         kinds = [self._kind(sc) for sc in dec_scales]
         main = "cfg" if "cfg" in kinds else kinds[0]  # the decoder scales that ride with the encoder (the others decode from z)
         ride = [j for j in range(n_dec) if kinds[j] == main and (main == "cfg" or dec_scales[j] == dec_scales[kinds.index(main)])]
+        bsz = image.shape[0]
+        enc_cfg = any(self._kind(float(sc)) == "cfg" for sc in self.encoder_unconditional_guidance_scales)
+        rows = bsz * ((2 if enc_cfg else 1) + len(ride) * (2 if main == "cfg" else 1))  # of one member's coupled forward
+        self.last_translate_coupled = bool(self.couple and whole and rows * self.image_size ** 2 <= self.couple_max_tokens)
+        if not self.last_translate_coupled:
+            z_ensemble = self.encode(image, encode_text)
+            return self.forward(z_ensemble, image, encode_text, decode_text)
+        x0, c_src, uc, members = self._encode_front(image, encode_text)
+        c_tgt, _ = self.get_condition(decode_text, bsz)
         z_ensemble, latents = [None] * len(members), {}
-        per_call = max(1, self.MAX_FOLD // (bsz * (1 + len(ride))))
+        per_call = max(1, min(self.MAX_FOLD // (bsz * (1 + len(ride))), self.couple_max_tokens // (rows * self.image_size ** 2)))
         for grp in self._groups([(m[0], m[1]) for m in members]):
             enc_scale, skip = members[grp[0]][0], members[grp[0]][1]
             for idx in self._chunks(grp, per_call):
