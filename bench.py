@@ -659,6 +659,10 @@ def main():
                        "parallelism": "dp%d" % world, "steps_per_launch_set": S, "launch_sets": sets,
                        "launch_set_cap": C, "launch_sets_in_flight_per_gpu": n_rep,
                        "images_in_flight_per_gpu": B * S * n_rep,
+                       "host_threads_per_rank": torch.get_num_threads(),
+                       # encode() + forward() as ONE loop - a forward per step over [encoder rows | decoder rows],
+                       # cd_cycle_translate - at this line's operating point (the wrapper couples below COUPLE_MAX_TOKENS)
+                       "coupled_loop": timed_coupled,
                        "distributed": "nccl(RCCL) process group" if dist.is_initialized() else "single process",
                        # CPU seconds of this rank (all threads) per wall second of the timed region: the launching thread
                        # sleeps in blocking-sync events (engine step pacing, cd_engine_synchronize)

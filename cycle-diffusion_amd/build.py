@@ -46,6 +46,10 @@ def build(force=False, verbose=False, variant=None):
         objdir = os.path.join(HERE, "build", "probe")
         lib = os.path.join(LIBDIR, "libcyclediff_probe.so")
         defines = ["-DCD_PROBE"]
+    elif variant == "pack8old":  # round-6 A/B: the f2bf-based pack8 / pack2 (measurement only)
+        objdir = os.path.join(HERE, "build", "pack8old")
+        lib = os.path.join(LIBDIR, "libcyclediff_pack8old.so")
+        defines = ["-DCD_PACK8_F2BF"]
     elif variant is not None:
         raise ValueError("unknown build variant %r" % (variant,))
     os.makedirs(LIBDIR, exist_ok=True)
@@ -82,4 +86,5 @@ def build(force=False, verbose=False, variant=None):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, variant="bf16" if "--bf16" in sys.argv else ("probe" if "--probe" in sys.argv else None)))
+    print(build(force="--force" in sys.argv, verbose=True, variant="bf16" if "--bf16" in sys.argv else ("probe" if "--probe" in sys.argv else
+                                                                   ("pack8old" if "--pack8old" in sys.argv else None))))

@@ -80,7 +80,7 @@ __device__ inline void unpack8(const uint4& raw, float* f) {
 #endif
 
 __device__ inline uint32_t pack2(float lo, float hi) {
-#if CD_ACT_FP16 && defined(__HIP_DEVICE_COMPILE__)  // two v_med3_f32 + one v_cvt_pk_f16_f32 (see pack8)
+#if CD_ACT_FP16 && defined(__HIP_DEVICE_COMPILE__) && !defined(CD_PACK8_F2BF)  // two v_med3_f32 + one v_cvt_pk_f16_f32 (see pack8)
   typedef __attribute__((ext_vector_type(2))) _Float16 h2;
   const h2 v = {(_Float16)__builtin_amdgcn_fmed3f(lo, -65504.0f, 65504.0f),
                 (_Float16)__builtin_amdgcn_fmed3f(hi, -65504.0f, 65504.0f)};
@@ -113,7 +113,7 @@ constexpr uint32_t kOnePair = 0x3F803F80u;
 // every k_conv_gemm tile spends 13-40 % of its time in its row passes). Same bits as f2bf for every non-NaN input; a NaN
 // saturates instead of passing through.
 __device__ inline uint4 pack8(const float* f) {
-#if CD_ACT_FP16 && defined(__HIP_DEVICE_COMPILE__)
+#if CD_ACT_FP16 && defined(__HIP_DEVICE_COMPILE__) && !defined(CD_PACK8_F2BF)  // (-DCD_PACK8_F2BF: the old form, A/B builds only)
   typedef __attribute__((ext_vector_type(2))) _Float16 h2;
   uint32_t w[4];
 #pragma unroll

@@ -1178,6 +1178,16 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   if (p.act == ACT_GEGLU && (ci->TN % 64) != 0) { id = 2; ci = &kCfgs[1]; }
   if (cfg_needs_bk64(id)) CD_CHECK(k64, "conv_gemm: tile configuration %d needs channel counts that are multiples of 64", id);
   g_last_cfg = ci->name;
+  // CYCLEDIFF_GEMM_TRACE=1: one line per launch, in launch order (scripts/pmc_traffic_by_shape.py matches them with the
+  // dispatches of a rocprofv3 counter pass: M N K KH stride up cat nbatch act resid out_f32 chm | tile)
+  static const bool trace = [] { const char* e = getenv("CYCLEDIFF_GEMM_TRACE"); return e && e[0] == '1'; }();
+  if (trace) {
+    const int64_t a_bytes = (int64_t)p.B * p.Hs * p.Ws * Ctot * 2;
+    const bool chm = id != kLinStreamTile && pk.korder != 0 && p.KH * p.KW > 1 && p.KH <= 8 && p.KW <= 8 && !p.up &&
+                     (pk.korder == 2 || (p.Hs * p.Ws >= 4096 && a_bytes >= (32ll << 20)));
+    fprintf(stderr, "[gemm_trace] %d %d %d %d %d %d %d %d %d %d %d %d | %s x%d\n", p.M, p.N, p.Ktot, p.KH, p.stride, p.up,
+            p.src1 ? 1 : 0, p.nbatch, p.act, p.resid ? 1 : 0, p.out_f32, chm ? 1 : 0, ci->name, pk.splitk > 1 ? pk.splitk : 1);
+  }
   KernelProfiler* prof = g_conv_prof;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (prof && prof->enabled) {

@@ -340,7 +340,10 @@ Act conv_fwd(Ctx& c, const ConvW& w, const Act& x, const Act* x2, const ConvOpts
 
 bool conv_ln_fold_available(const Ctx& c, const ConvW& w, int64_t rows) {
   static const bool on = [] { const char* e = getenv("CYCLEDIFF_LN_FOLD"); return !(e && e[0] == '0'); }();  // A/B runs
-  return on && !c.f32 && w.wfrag && w.KH == 1 && w.KW == 1 && w.Cpad == 320 && rows >= 65536 && rows % 32 == 0 &&
+  // the streaming kernel owns 256-row strips, one persistent workgroup per CU: below ~3/4 of the CUs' worth of strips the
+  // tile kernel + a LayerNorm launch is the better pair (CYCLEDIFF_LN_FOLD_MIN_ROWS overrides the threshold for A/B runs)
+  static const int64_t min_rows = [] { const char* e = getenv("CYCLEDIFF_LN_FOLD_MIN_ROWS"); return e ? atoll(e) : 32768ll; }();
+  return on && !c.f32 && w.wfrag && w.KH == 1 && w.KW == 1 && w.Cpad == 320 && rows >= min_rows && rows % 32 == 0 &&
          w.N % 64 == 0 && w.N <= 2560;
 }
 

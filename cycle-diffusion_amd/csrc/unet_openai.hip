@@ -87,6 +87,8 @@ class UNetOpenAI : public UNet {
   // (UNetIO::dup_tail; a classifier-free-guidance batch is dup_tail = x.B); everything ahead of the cross-attention runs on
   // x, then the token stream and the block input get the repeated samples appended and the rest runs on x.B + dup_tail
   Act st_fwd(Ctx& c, STW& s, const Act& x, int dup_tail = 0);
+  // the block on images [b0, b0 + x.B) of the batch the context was set for, into the caller's output rows
+  void st_core16(Ctx& c, STW& s, const Act& x_in, const Act& x_resid, Act& out, int b0, int dup_tail);
   Act ab_fwd(Ctx& c, const ABW& a, const Act& x);
  public:
   ~UNetOpenAI() override { for (void* p : ctx_allocs_) (void)hipFree(p); }
@@ -419,11 +421,11 @@ Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x_in, int dup_tail) {
   }
   const size_t mk = c.arena->mark();
   CD_CHECK(s.k2c && ctx_B_ == B + dup_tail, "cross-attention context not set for batch %d", B + dup_tail);
-  ConvOpts p0; p0.pad = 0;
-  Act n = groupnorm_fwd(c, s.norm, x_in, nullptr, false);
-  Act h = conv_fwd(c, *s.proj_in, n, nullptr, p0);  // tokens [B*T][C]
-  const float scale = 1.0f / sqrtf((float)s.dh);
   if (c.f32) {
+    ConvOpts p0; p0.pad = 0;
+    Act n = groupnorm_fwd(c, s.norm, x_in, nullptr, false);
+    Act h = conv_fwd(c, *s.proj_in, n, nullptr, p0);  // tokens [B*T][C]
+    const float scale = 1.0f / sqrtf((float)s.dh);
     // CD_PREC_F32 / F32X3 (st_f32.hip): the reference's own arithmetic for this block (`precision = "full"`,
     // stable_diffusion_stochastic_text_wrapper.py:117). LayerNorm / GroupNorm outputs feed their projections as fp32 (k_conv_f32)
     // or, in the split mode, as fp16 pairs (three-term products on the 16-bit matrix cores) - there the attention output, the
@@ -491,6 +493,44 @@ Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x_in, int dup_tail) {
     c.arena->release(mk);
     return out;
   }
+  // 16-bit path. Every image is independent through the whole block: at the 64 x 64 level a large batch runs depth-first in
+  // chunks of ST_CHUNK images, so that the chunk's token tensors (42 MB per 320-channel tensor and 16 images, 168 MB for the
+  // GEGLU hidden tensor) stay in the 256 MB Infinity Cache between the block's ~15 kernels instead of making an HBM round
+  // trip each - the N = K = 320 projections, the norm passes and the feed-forward pair are bound by exactly those trips
+  // (DESIGN.md 8). Chunks of 16 images are 65 536 rows: 256 strips / row tiles, one full round of the chip per kernel.
+  static const int st_chunk = [] { const char* e = getenv("CYCLEDIFF_ST_CHUNK"); return e ? atoi(e) : 0; }();
+  c.arena->release(mk);
+  if (!dup && st_chunk > 0 && T >= 4096 && B >= 2 * st_chunk) {
+    for (int b0 = 0; b0 < B; b0 += st_chunk) {
+      const int n = std::min(st_chunk, B - b0);
+      auto view = [&](const Act& a) {
+        Act v = a; v.B = n;
+        v.p = a.p + (int64_t)b0 * T * a.ld;
+        if (a.stats) v.stats = a.stats + ((int64_t)b0 * T / 32) * 2 * a.C;
+        if (a.stats_buf) v.stats_buf = a.stats_buf + ((int64_t)b0 * T / 32) * 2 * a.C;
+        return v;
+      };
+      Act xv = view(x_in), ov = view(out);
+      st_core16(c, s, xv, xv, ov, b0, 0);
+    }
+  } else {
+    st_core16(c, s, x_in, x, out, 0, dup_tail);
+  }
+  out.stats = out.stats_buf;
+  return out;
+}
+
+void UNetOpenAI::st_core16(Ctx& c, STW& s, const Act& x_in, const Act& x, Act& out, int b0, int dup_tail) {
+  const bool dup = dup_tail > 0;
+  int B = x_in.B;
+  const int T = x_in.H * x_in.W, C = s.C;
+  const size_t mk = c.arena->mark();
+  ConvOpts p0; p0.pad = 0;
+  const float scale = 1.0f / sqrtf((float)s.dh);
+  const bf16_t* k2c = s.k2c + (int64_t)b0 * ctx_L_ * C;
+  const bf16_t* v2c = s.v2c + (int64_t)b0 * ctx_L_ * C;
+  Act n = groupnorm_fwd(c, s.norm, x_in, nullptr, false);
+  Act h = conv_fwd(c, *s.proj_in, n, nullptr, p0);  // tokens [B*T][C]
   {  // self-attention
     const size_t m2 = c.arena->mark();
     Act n1 = layernorm_fwd(c, s.ln1, h);
@@ -528,7 +568,7 @@ Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x_in, int dup_tail) {
       Act n2 = layernorm_fwd(c, s.ln2, h);
       q = conv_fwd(c, *s.q2, n2, nullptr, p0);
     }
-    Act a = attention_fwd(c, q.p, q.ld, s.k2c, C, s.v2c, C, B, s.heads, T, ctx_L_, s.dh, scale, x.H, x.W,
+    Act a = attention_fwd(c, q.p, q.ld, k2c, C, v2c, C, B, s.heads, T, ctx_L_, s.dh, scale, x.H, x.W,
                           /*q_log2=*/true);
     ConvOpts o; o.pad = 0; o.resid = &h; o.out = h.p; o.out_ld = h.ld;  // in-place residual update
     conv_fwd(c, *s.o2, a, nullptr, o);
@@ -550,9 +590,7 @@ Act UNetOpenAI::st_fwd(Ctx& c, STW& s, const Act& x_in, int dup_tail) {
   }
   ConvOpts po; po.pad = 0; po.resid = &x; po.out = out.p; po.out_ld = out.ld; po.out_stats = out.stats_buf;
   conv_fwd(c, *s.proj_out, h, nullptr, po);
-  out.stats = out.stats_buf;
   c.arena->release(mk);
-  return out;
 }
 
 Act UNetOpenAI::ab_fwd(Ctx& c, const ABW& a, const Act& x) {

@@ -35,9 +35,14 @@ def read_table(path):
     return rows
 
 
+MIN_M = int(os.environ.get("INPATH_MIN_M", "4096"))
+MAX_K = int(os.environ.get("INPATH_MAX_K", "1280"))
+ONLY_M = [int(x) for x in os.environ.get("INPATH_ONLY_M", "").split(",") if x]  # restrict to the row counts of one batch size
+
+
 def is_target(k):
     M, N, K, KH, C0, C1, stride, up, act, nbatch = k[:10]
-    return KH == 1 and K <= 1280 and nbatch == 1 and M >= 4096 and K % 32 == 0
+    return KH == 1 and K <= MAX_K and nbatch == 1 and M >= MIN_M and K % 32 == 0 and (not ONLY_M or M in ONLY_M)
 
 
 def label_key(k):  # what the GEMM log prints for a table key
