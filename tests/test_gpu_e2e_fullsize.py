@@ -667,15 +667,15 @@ class _BlockNoise:
         return out
 
 
-@pytest.mark.parametrize("mode", ["batch4", "batch4_coupled", "slots_of_64"])
-def test_c2_four_triplets_per_reference_call_skip20_scales_1_and_3(report, mode):
+def test_c2_four_triplets_per_reference_call_skip20_scales_1_and_3(report):
     """tests/golden/c2_sd512_b4_e2e.npz (oracle/gen_golden_full.py --only c2b4, 2 CPU-hours): the reference's UNetModel /
     Encoder / Decoder / DDIMSampler on FOUR triplets in ONE call of every function - the batch size of its own harness
     (README.md:153 --per_device_eval_batch_size 4) - with skip_steps [20], encoder scale 1 and decoder scales [1, 3]; images,
-    twelve contexts and the noise stream on other seeds than c2_sd512_e2e. Here: the wrapper on the same four triplets in one
-    call (two loops, and the coupled loop through translate's machinery), and the four triplets as slots 5 / 21 / 38 / 60 of a
-    64-image batch - the benchmarked launch set of 16 steps. Every one of the 8 candidate images >= 50 dB against the
-    reference's (bf16 build: 34)."""
+    twelve contexts and the noise stream on other seeds than c2_sd512_e2e. Here, on one wrapper: (batch4) the same four
+    triplets in one call of encode() / generate(); (batch4_coupled) through translate()'s coupled loop - the guided scale
+    rides with the encoder, the scale-1 candidate decodes from the returned z; (slots_of_64) the four triplets as slots
+    5 / 21 / 38 / 60 of a 64-image batch - the benchmarked launch set of 16 steps. Every one of the 8 candidate images
+    >= 50 dB against the reference's (bf16 build: 34)."""
     path = os.path.join(gu.GOLD, "c2_sd512_b4_e2e.npz")
     if not os.path.exists(path):
         pytest.skip("fixture c2_sd512_b4_e2e not generated")
@@ -694,38 +694,43 @@ def test_c2_four_triplets_per_reference_call_skip20_scales_1_and_3(report, mode)
         sd = nets.synth_state_dict(json.loads(str(fx[key])), seed)
         assert w.engine.load_state_dict(net, sd)[0] == 0
         del sd
-    B = 64 if mode == "slots_of_64" else 4
-    slots = [5, 21, 38, 60] if mode == "slots_of_64" else [0, 1, 2, 3]
-    w.MAX_FOLD = max(w.MAX_FOLD, B)
-    img_seeds = [seeds["image"][slots.index(b)] if b in slots else 1000 + b for b in range(B)]
-    src = ["seed:%d" % (seeds["c_src"][slots.index(b)] if b in slots else 2000 + b) for b in range(B)]
-    tgt = ["seed:%d" % (seeds["c_tgt"][slots.index(b)] if b in slots else 3000 + b) for b in range(B)]
-    images = torch.cat([torch.rand((1, 3, 512, 512), generator=torch.Generator().manual_seed(s)) for s in img_seeds], 0)
-    w.noise_source = _BlockNoise(seeds["noise"], slots, B)
-    cands = []
-    if mode == "batch4_coupled":  # translate() ranks; its candidates are what generate() returns
-        real_select = w._select
-        w._select = lambda imgs, *a: (cands.extend(imgs), real_select(imgs, *a))[1]
-    with torch.no_grad():
-        x = images.cuda()
-        if mode == "batch4_coupled":
-            w.translate(x, src, tgt)
-            assert w.last_translate_coupled
-            z = None
-        else:
-            z_ens = w.encode(x, src)
-            cands = w.generate(z_ens, tgt)
-            z = z_ens[0].view(B, int(fx["white_box_steps"]) - skip, 4, 64, 64)[slots].cpu()
-    assert len(cands) == len(scales) and all(c.shape == (B, 3, 512, 512) for c in cands)
     ref = torch.as_tensor(fx["img"]).float()  # [scale][4][3][512][512]
-    ps = [[gu.psnr(cands[j][b:b + 1].cpu(), ref[j, i:i + 1]) for i, b in enumerate(slots)] for j in range(len(scales))]
-    row = dict(psnr_db_scale_by_triplet=ps, reference_cpu_seconds=float(fx["cpu_seconds"]), batch=B)
-    if z is not None:
-        zr, sl = torch.as_tensor(fx["z_sub"]), [int(s) for s in fx["z_sub_slots"]]
-        row["xT_maxabs"] = (z[:, 0] - zr[:, 0]).abs().max().item()
-        row["eps_rel_slots"] = [((z[:, s] - zr[:, i]).abs().max() / zr[:, i].abs().max()).item() for i, s in enumerate(sl) if s > 0]
-        zn = torch.as_tensor(fx["z_norms"])
-        row["z_norm_rel"] = ((z.flatten(2).norm(dim=2) - zn).abs() / zn).max().item()
-        assert row["z_norm_rel"] < 2e-3 * FMT and max(row["eps_rel_slots"]) < 5e-2 * FMT, row
-    report.add("e2e/c2_sd512_b4_" + mode, **row)
-    assert min(min(p) for p in ps) >= PSNR_FLOOR, ps
+    real_select = w._select
+    for mode in ("batch4", "batch4_coupled", "slots_of_64"):
+        B = 64 if mode == "slots_of_64" else 4
+        slots = [5, 21, 38, 60] if mode == "slots_of_64" else [0, 1, 2, 3]
+        w.MAX_FOLD = max(w.MAX_FOLD, B)
+        img_seeds = [seeds["image"][slots.index(b)] if b in slots else 1000 + b for b in range(B)]
+        src = ["seed:%d" % (seeds["c_src"][slots.index(b)] if b in slots else 2000 + b) for b in range(B)]
+        tgt = ["seed:%d" % (seeds["c_tgt"][slots.index(b)] if b in slots else 3000 + b) for b in range(B)]
+        images = torch.cat([torch.rand((1, 3, 512, 512), generator=torch.Generator().manual_seed(s)) for s in img_seeds], 0)
+        w.noise_source = _BlockNoise(seeds["noise"], slots, B)
+        cands, z = [], None
+        with torch.no_grad():
+            x = images.cuda()
+            if mode == "batch4_coupled":  # translate() ranks; its candidates are what generate() returns
+                w._select = lambda imgs, *a: (cands.extend(imgs), real_select(imgs, *a))[1]
+                try:
+                    w.translate(x, src, tgt)
+                finally:
+                    w._select = real_select
+                assert w.last_translate_coupled
+            else:
+                z_ens = w.encode(x, src)
+                cands = w.generate(z_ens, tgt)
+                z = z_ens[0].view(B, int(fx["white_box_steps"]) - skip, 4, 64, 64)[slots].cpu()
+        assert len(cands) == len(scales) and all(c.shape == (B, 3, 512, 512) for c in cands)
+        ps = [[gu.psnr(cands[j][b:b + 1].cpu(), ref[j, i:i + 1]) for i, b in enumerate(slots)] for j in range(len(scales))]
+        row = dict(psnr_db_scale_by_triplet=ps, reference_cpu_seconds=float(fx["cpu_seconds"]), batch=B)
+        if z is not None:
+            zr, sl = torch.as_tensor(fx["z_sub"]), [int(s) for s in fx["z_sub_slots"]]
+            row["xT_maxabs"] = (z[:, 0] - zr[:, 0]).abs().max().item()
+            row["eps_rel_slots"] = [((z[:, s] - zr[:, i]).abs().max() / zr[:, i].abs().max()).item()
+                                    for i, s in enumerate(sl) if s > 0]
+            zn = torch.as_tensor(fx["z_norms"])
+            row["z_norm_rel"] = ((z.flatten(2).norm(dim=2) - zn).abs() / zn).max().item()
+            assert row["z_norm_rel"] < 2e-3 * FMT and max(row["eps_rel_slots"]) < 5e-2 * FMT, row
+        report.add("e2e/c2_sd512_b4_" + mode, **row)
+        assert min(min(p) for p in ps) >= PSNR_FLOOR, (mode, ps)
+        del cands, x, images
+        torch.cuda.empty_cache()
