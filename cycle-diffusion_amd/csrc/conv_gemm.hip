@@ -132,7 +132,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
   // there, so the 8 XCDs do not each fetch the whole weight matrix (same speed, ~20 % less HBM-side traffic).
   const bool nmajor = (int64_t)p.N * p.Ktot > (int64_t)p.B * p.Hs * p.Ws * (p.C0 + p.C1);
   int tm, tn;
-  if (nmajor) { tn = tile / tiles_m; tm = tile - tn * tiles_m; }
+  if (p.tile_group > 0) {  // grouped walk: G row tiles at a time, m fastest inside the group
+    const int width = p.tile_group * tiles_n;
+    const int grp = tile / width, within = tile - grp * width;
+    const int first_m = grp * p.tile_group;
+    const int gsz = (tiles_m - first_m) < p.tile_group ? (tiles_m - first_m) : p.tile_group;
+    tn = within / gsz; tm = first_m + (within - tn * gsz);
+  } else if (nmajor) { tn = tile / tiles_m; tm = tile - tn * tiles_m; }
   else { tm = tile / tiles_n; tn = tile - tm * tiles_n; }
   const int m0 = tm * BM, n0 = tn * BN;
   const int zb = blockIdx.z;
@@ -1162,6 +1168,12 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   pk.probe = g_conv_probe;
   static const int korder_env = [] { const char* e = getenv("CYCLEDIFF_KORDER"); return e ? atoi(e) : -1; }();
   if (korder_env >= 0) pk.korder = korder_env;
+  // grouped tile walk for wide-N contractions (>= CYCLEDIFF_TILE_GROUP_MIN_N column tiles of 256): both operands exceed an
+  // XCD's 4 MiB L2 and a row-major walk re-streams one of them for every tile row / column (round-6 per-shape counters:
+  // GEGLU 1280 -> 10240 at 16 x 16 reads 26x its algorithmic bytes, 640 -> 5120 at 32 x 32 14x)
+  static const int tg_env = [] { const char* e = getenv("CYCLEDIFF_TILE_GROUP"); return e ? atoi(e) : 0; }();
+  static const int tg_min_n = [] { const char* e = getenv("CYCLEDIFF_TILE_GROUP_MIN_N"); return e ? atoi(e) : 2048; }();
+  if (tg_env > 0 && p.N >= tg_min_n && p.nbatch == 1) pk.tile_group = tg_env;
 #ifdef CD_PROBE
   if (const char* e = getenv("CYCLEDIFF_PROBE_DBG")) pk.dbg = atoi(e);
   if (pk.dbg & 2) pk.stats = nullptr;

@@ -103,6 +103,10 @@ struct ConvGemmParams {
   // of the 320-channel 3 x 3 conv at 64 x 64 750 -> 409 MB per launch). 1 (default) = channel-major where the activation is
   // large (launch_cfg), 2 = wherever the kernel supports it, 0 = never (CYCLEDIFF_KORDER for A/B runs)
   int korder = 1;
+  // tile walk inside an XCD's contiguous range: 0 = row-major in the operand the launcher picked (m-major / n-major);
+  // G > 0 = groups of G row tiles walked m-fastest (the 32 CUs of an XCD then run G row tiles x 32 / G column tiles at a time:
+  // G A panels + 32 / G W panels in its L2 instead of 1 + 32) - for the wide-N layers whose operands both exceed the L2
+  int tile_group = 0;
   int dbg = 0;  // probe build: 1 = the epilogue skips its global stores, 2 = skips the statistics, 4 = every tile gathers
                 // its A rows from the first 1024 + BM rows (an L2-resident operand: what would the K loop do without misses?)
 };

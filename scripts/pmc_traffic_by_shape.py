@@ -27,10 +27,8 @@ def main():
     fetch = dispatches(sys.argv[1], "FETCH_SIZE")
     write = dispatches(sys.argv[2], "WRITE_SIZE")
     trace = [ln.split("]", 1)[1].strip() for ln in open(sys.argv[3], errors="replace") if ln.startswith("[gemm_trace]")]
-    # forwards of bench_unet.py: identical launch sequences; the period is found from the trace itself
-    first = trace[0]
-    starts = [i for i, t in enumerate(trace) if t == first]
-    per = next((b - a for a, b in zip(starts, starts[1:]) if trace[a:b] == trace[b:b + (b - a)]), len(trace))
+    # forwards of bench_unet.py: identical launch sequences; the period is the shortest tail that repeats itself
+    per = next((q for q in range(50, len(trace) // 2 + 1) if trace[-q:] == trace[-2 * q:-q]), len(trace))
     last = trace[-per:]
     assert len(fetch) >= per and len(write) >= per, (len(fetch), len(write), per)
     f, w = fetch[-per:], write[-per:]
