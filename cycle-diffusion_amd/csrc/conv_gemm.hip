@@ -1171,7 +1171,10 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   // grouped tile walk for wide-N contractions (>= CYCLEDIFF_TILE_GROUP_MIN_N column tiles of 256): both operands exceed an
   // XCD's 4 MiB L2 and a row-major walk re-streams one of them for every tile row / column (round-6 per-shape counters:
   // GEGLU 1280 -> 10240 at 16 x 16 reads 26x its algorithmic bytes, 640 -> 5120 at 32 x 32 14x)
-  static const int tg_env = [] { const char* e = getenv("CYCLEDIFF_TILE_GROUP"); return e ? atoi(e) : 0; }();
+  // Measured (profiles/r6_conv_gemm_traffic_by_shape_b64_group8.json, r6_tile_group_ab.json): groups of 8 cut those two layers'
+  // fetch to 9x / 7x and the forward's GEMM reads from 2.31x to 2.03x of algorithmic at unchanged speed (the layers are bound by
+  // their GEGLU epilogues, not by the fabric) - on by default for N >= 2048; CYCLEDIFF_TILE_GROUP=0 restores the row-major walk
+  static const int tg_env = [] { const char* e = getenv("CYCLEDIFF_TILE_GROUP"); return e ? atoi(e) : 8; }();
   static const int tg_min_n = [] { const char* e = getenv("CYCLEDIFF_TILE_GROUP_MIN_N"); return e ? atoi(e) : 2048; }();
   if (tg_env > 0 && p.N >= tg_min_n && p.nbatch == 1) pk.tile_group = tg_env;
 #ifdef CD_PROBE
