@@ -525,6 +525,8 @@ def main():
     folded = {n: (images[:n].reshape(n * (hi - lo), 3, R, R), sample_id.repeat(n), sum(src[:n], []), sum(tgt[:n], []))
               for n in set(sets) | {1 if single else 0} if n}
 
+    coupled_by_set = {}  # launch-set size (steps) -> did translate() take the coupled loop (None: wrapper has none)
+
     def compute(r, n):
         """one launch set of n steps (n * B triplets) on replica r"""
         st, m = replicas[r]
@@ -532,8 +534,12 @@ def main():
         torch.cuda.set_device(dev)  # the current device is per host thread
         with torch.cuda.stream(st), torch.no_grad():
             if wl["text"]:
-                return m(sample_id=sid, original_image=im, encode_text=s_txt, decode_text=t_txt)
-            return m(sample_id=sid, original_image=im)
+                out = m(sample_id=sid, original_image=im, encode_text=s_txt, decode_text=t_txt)
+            else:
+                out = m(sample_id=sid, original_image=im)
+        w_r = getattr(m, "gan_wrapper", None)
+        coupled_by_set[n] = getattr(w_r, "last_translate_coupled", None)
+        return out
 
     def gather(r, res):
         """the per-step all-gather (trainer.py:833), once per step of the launch set, in step order"""
@@ -603,7 +609,7 @@ def main():
     # BASELINE's literal operating point beside the folded one: launch sets of ONE step (a batch of B triplets per
     # engine call, B' = B through the DPM-Encoder), timed the same way on every rank
     single_dt, single_coupled = None, None
-    timed_coupled = getattr(wrapper, "last_translate_coupled", None)  # of the timed launch sets
+    timed_coupled = {str(n): coupled_by_set.get(n) for n in sorted(set(sets), reverse=True)}  # by launch-set size (steps)
     if single:
         gather(0, compute(0, 1))
         sync()
@@ -612,7 +618,7 @@ def main():
             gather(0, compute(0, 1))
         sync()
         single_dt = time.perf_counter() - t1
-        single_coupled = getattr(wrapper, "last_translate_coupled", None)
+        single_coupled = coupled_by_set.get(1)
         if dist.is_initialized():
             tt = torch.tensor([single_dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -661,8 +667,8 @@ def main():
                        "images_in_flight_per_gpu": B * S * n_rep,
                        "host_threads_per_rank": torch.get_num_threads(),
                        # encode() + forward() as ONE loop - a forward per step over [encoder rows | decoder rows],
-                       # cd_cycle_translate - at this line's operating point (the wrapper couples below COUPLE_MAX_TOKENS)
-                       "coupled_loop": timed_coupled,
+                       # cd_cycle_translate - by launch-set size in steps (the wrapper couples below COUPLE_MAX_TOKENS)
+                       "coupled_loop_by_launch_set": timed_coupled,
                        "distributed": "nccl(RCCL) process group" if dist.is_initialized() else "single process",
                        # CPU seconds of this rank (all threads) per wall second of the timed region: the launching thread
                        # sleeps in blocking-sync events (engine step pacing, cd_engine_synchronize)
