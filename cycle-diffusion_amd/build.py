@@ -50,6 +50,10 @@ def build(force=False, verbose=False, variant=None):
         objdir = os.path.join(HERE, "build", "pack8old")
         lib = os.path.join(LIBDIR, "libcyclediff_pack8old.so")
         defines = ["-DCD_PACK8_F2BF"]
+    elif variant == "geluold":  # round-6 A/B: the select form of gelu_fast (measurement only)
+        objdir = os.path.join(HERE, "build", "geluold")
+        lib = os.path.join(LIBDIR, "libcyclediff_geluold.so")
+        defines = ["-DCD_GELU_SELECT_FORM"]
     elif variant is not None:
         raise ValueError("unknown build variant %r" % (variant,))
     os.makedirs(LIBDIR, exist_ok=True)
@@ -87,4 +91,5 @@ def build(force=False, verbose=False, variant=None):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True, variant="bf16" if "--bf16" in sys.argv else ("probe" if "--probe" in sys.argv else
-                                                                   ("pack8old" if "--pack8old" in sys.argv else None))))
+                                                                   ("pack8old" if "--pack8old" in sys.argv else
+                                                                    ("geluold" if "--geluold" in sys.argv else None)))))

@@ -156,20 +156,33 @@ __device__ inline float silu_acc(float x) { return x / (1.0f + expf(-x)); }
 // exact-erf GELU (reference: F.gelu default, attention.py:44)
 __device__ inline float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// exact-erf GELU for the 16-bit epilogues: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. far
-// below the 2^-11 relative step of the fp16 value the result is stored as); 0.5 x (1 + erf(x / sqrt 2)) evaluated as
-// 0.5 x q for x < 0 and 0.5 x (2 - q) otherwise, q = poly(t) exp(-x^2 / 2), so the negative tail does not cancel.
-// 13 VALU operations instead of ~35 for erff: the GEGLU layers are 17 % of the GEMM time and epilogue-bound.
+// exact-erf GELU for the 16-bit epilogues: erfc by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. far below the
+// 2^-11 relative step of the fp16 value the result is stored as): q = poly(t) t exp(-x^2 / 2), t = 1 / (1 + p |x| / sqrt 2), and
+//   gelu(x) = 0.5 x (1 + erf(x / sqrt 2)) = max(x, 0) - 0.5 |x| q        (x >= 0: x - 0.5 x q;  x < 0: -0.5 |x| q)
+// - no select, the 0.5 lives in the polynomial's coefficients, |x| is an operand modifier, and the negative tail does not
+// cancel. Round 6: 13 VALU operations (two of them quarter-rate: v_rcp_f32, v_exp_f32) instead of 16 - the GEGLU
+// projections are 19 % of the GEMM time and VALU-bound in their epilogues; ~35 for erff.
+// Measured against fp64 erf over [-12, 12]: |error| <= 3.4e-7 absolute.
 __device__ inline float gelu_fast(float x) {
 #pragma clang fp contract(off)  // the same bits wherever it is inlined (conv_gemm.hip and lin_stream.hip must agree)
+#ifdef CD_GELU_SELECT_FORM  // rounds 3-5: 0.5 x (x < 0 ? q : 2 - q), 16 operations (A/B builds only: build.py --geluold)
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
-  float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
-  poly = __builtin_fmaf(t, poly, 1.421413741f);
-  poly = __builtin_fmaf(t, poly, -0.284496736f);
-  poly = __builtin_fmaf(t, poly, 0.254829592f);
-  const float q = poly * t * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+  const float tt = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float pp = __builtin_fmaf(tt, 1.061405429f, -1.453152027f);
+  pp = __builtin_fmaf(tt, pp, 1.421413741f);
+  pp = __builtin_fmaf(tt, pp, -0.284496736f);
+  pp = __builtin_fmaf(tt, pp, 0.254829592f);
+  const float q = pp * tt * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
   return 0.5f * x * (x < 0.0f ? q : 2.0f - q);
+#endif
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.231641888f, ax, 1.0f));  // 0.3275911 / sqrt 2
+  float poly = __builtin_fmaf(t, 0.5307027145f, -0.7265760135f);                   // A-S coefficients, halved
+  poly = __builtin_fmaf(t, poly, 0.7107068705f);
+  poly = __builtin_fmaf(t, poly, -0.142248368f);
+  poly = __builtin_fmaf(t, poly, 0.127414796f);
+  const float e = __builtin_amdgcn_exp2f(-(x * x) * 0.72134752f);                  // exp(-x^2 / 2)
+  return fmaxf(x, 0.0f) - poly * t * e * ax;
 }
 
 // ---- error handling: no exception crosses the C ABI -----------------------------------------

@@ -7,6 +7,7 @@
   python -m oracle.gen_golden_full --only c2ens   (~25 min; the SD wrapper's ensemble loops, SD-sized nets at 256 x 256)
   python -m oracle.gen_golden_full --only c5      (~30 min; the same with the reference's full 1000 / 850 / 100 chain)
   python -m oracle.gen_golden_full --only c2b4    (~2 h; config 2 with FOUR triplets per reference call, skip 20, scales [1, 3])
+  python -m oracle.gen_golden_full --only c3b16   (~70 min; config 3 with SIXTEEN triplets per reference call, skip 30, scale 2)
 
 One (image, source-text, target-text) triplet per BASELINE configuration, run the way the reference's
 text wrapper composes it (stable_diffusion_stochastic_text_wrapper.py:169-249): VAE encode -> posterior
@@ -211,6 +212,54 @@ def gen_c2_b4():
          cpu_threads=torch.get_num_threads())
 
 
+def gen_c3_b16():
+    """BASELINE config 3 at ITS batch size in one reference call: LDM text2img-large shapes, 256 x 256, SIXTEEN triplets per
+    call of every reference function (README.md:195 `--per_device_eval_batch_size 16`), posterior mean
+    (latentdiff ddpm.py:535-538), `skip_steps = [30]`, encoder scale 1, decoder scale 2; other seeds than c3_ldm256_e2e.
+    ~70 min on 8 threads (69 encoder forwards at B = 16, 69 decoder forwards at B = 32)."""
+    ref_import.setup()
+    from ldm.modules.distributions.distributions import DiagonalGaussianDistribution
+    Sampler = ref_import.ddim_sampler_cls()
+    res, steps, eta, wb, B = 256, 99, 0.1, 100, 16
+    skip, dec_scale = 30, 2.0
+    seeds = dict(unet=SEEDS["unet"], vae=SEEDS["vae"], image=list(range(301, 301 + B)), c_src=list(range(331, 331 + B)),
+                 c_tgt=list(range(361, 361 + B)), uc=391, noise=4048)
+    t0 = time.time()
+    with torch.no_grad():
+        u = build_ref_sd_unet(LDM_UNET)
+        uns, _ = load_synth(u, seeds["unet"])
+        v = RefVAE(FULL_VAE)
+        vns, _ = load_synth(v, seeds["vae"])
+        shim = ref_import.LatentShim(u)
+        lat = res // 8
+        image = torch.cat([torch.rand((1, 3, res, res), generator=torch.Generator().manual_seed(s))
+                           for s in seeds["image"]], 0)
+        c_src = torch.cat([rnd((1, 77, 1280), s) for s in seeds["c_src"]], 0)
+        c_tgt = torch.cat([rnd((1, 77, 1280), s) for s in seeds["c_tgt"]], 0)
+        uc = rnd((1, 77, 1280), seeds["uc"]).repeat(B, 1, 1)
+        torch.manual_seed(seeds["noise"])
+        x0 = torch.cat([DiagonalGaussianDistribution(v.moments((image[i:i + 4] - 0.5) * 2.0)).mode() for i in range(0, B, 4)],
+                       0) * 0.18215
+        print("c3_b16: vae encode done", time.time() - t0, flush=True)
+        with ref_import.quiet():
+            z_list = Sampler(shim).ddpm_ddim_encoding(steps, conditioning=c_src, batch_size=B, shape=(4, lat, lat), eta=eta,
+                                                      white_box_steps=wb, skip_steps=skip, verbose=False, x0=x0,
+                                                      unconditional_guidance_scale=1, unconditional_conditioning=uc)
+        z = torch.stack(z_list, dim=1)
+        print("c3_b16: encode done", time.time() - t0, flush=True)
+        with ref_import.quiet():
+            x, _ = Sampler(shim).sample_with_eps(steps, z[:, 1:], conditioning=c_tgt, batch_size=B, shape=(4, lat, lat),
+                                                 eta=eta, verbose=False, x_T=z[:, 0], skip_steps=skip,
+                                                 unconditional_guidance_scale=dec_scale, unconditional_conditioning=uc)
+        img = torch.cat([(v.decode(x[i:i + 2] / 0.18215) + 1.0) / 2.0 for i in range(0, B, 2)], 0)
+        print("c3_b16: decoded", time.time() - t0, flush=True)
+    slots = [0, 1, 35, wb - skip - 1]
+    save("c3_ldm256_b16_e2e", unet_names=json.dumps(uns), vae_names=json.dumps(vns), seeds=json.dumps(seeds), steps=steps,
+         eta=eta, white_box_steps=wb, skip_steps=np.asarray([skip]), dec_scales=np.asarray([dec_scale]), x0=x0,
+         z_sub=z[:, slots], z_sub_slots=np.asarray(slots), z_norms=z.flatten(2).norm(dim=2), lat=x,
+         img=img.to(torch.float16), cpu_seconds=time.time() - t0, cpu_threads=torch.get_num_threads())
+
+
 LDM_UNCOND_UNET = dict(image_size=64, in_channels=3, out_channels=3, model_channels=224, attention_resolutions=[8, 4, 2],
                        num_res_blocks=2, channel_mult=[1, 2, 3, 4], num_head_channels=32)  # celeba256 / ffhq256 config.yaml:17-34
 
@@ -312,3 +361,5 @@ if __name__ == "__main__":
         gen_ldm_uncond_full()
     if a.only == "c2b4":  # ~2 h: only on request
         gen_c2_b4()
+    if a.only == "c3b16":  # ~70 min: only on request
+        gen_c3_b16()

@@ -734,3 +734,64 @@ def test_c2_four_triplets_per_reference_call_skip20_scales_1_and_3(report):
         assert min(min(p) for p in ps) >= PSNR_FLOOR, (mode, ps)
         del cands, x, images
         torch.cuda.empty_cache()
+
+
+def test_c3_sixteen_triplets_per_reference_call_skip30_scale_2(report):
+    """tests/golden/c3_ldm256_b16_e2e.npz (oracle/gen_golden_full.py --only c3b16): BASELINE config 3 at ITS batch size - the
+    reference's LDM-shaped UNetModel / Encoder / Decoder / DDIMSampler on SIXTEEN triplets in one call of every function
+    (README.md:195), posterior mean, `skip_steps [30]`, decoder scale 2; other seeds than c3_ldm256_e2e. Here on one wrapper:
+    the sixteen triplets in one call of encode() / generate(), through translate()'s coupled loop (48 rows of 32 x 32 tokens per
+    forward), and as every fourth slot of a 64-image batch (config 3's launch set of 4 steps). Every image >= 50 dB (bf16: 34)."""
+    path = os.path.join(gu.GOLD, "c3_ldm256_b16_e2e.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture c3_ldm256_b16_e2e not generated")
+    fx = np.load(path, allow_pickle=False)
+    seeds = json.loads(str(fx["seeds"]))
+    S, skip, scale, n = int(fx["steps"]), int(fx["skip_steps"][0]), float(fx["dec_scales"][0]), len(seeds["image"])
+    os.environ["CYCLEDIFF_SYNTHETIC_WEIGHTS"] = "1"
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        w = LatentDiffStochasticTextWrapper(source_model_type="text2img-large", custom_steps=S, eta=float(fx["eta"]),
+                                            white_box_steps=int(fx["white_box_steps"]), skip_steps=[skip],
+                                            encoder_unconditional_guidance_scales=[1.0],
+                                            decoder_unconditional_guidance_scales=[scale], n_trials=1,
+                                            cond_stage=_ListEmbedder(1280, seeds["uc"]), noise_on_cpu=True)
+    for net, key, seed in ((w.unet, "unet_names", seeds["unet"]), (w.vae, "vae_names", seeds["vae"])):
+        sd = nets.synth_state_dict(json.loads(str(fx[key])), seed)
+        assert w.engine.load_state_dict(net, sd)[0] == 0
+        del sd
+    ref = torch.as_tensor(fx["img"]).float()  # [16][3][256][256]
+    for mode in ("batch16", "batch16_coupled", "slots_of_64"):
+        B = 64 if mode == "slots_of_64" else n
+        slots = list(range(1, 64, 4)) if mode == "slots_of_64" else list(range(n))
+        w.MAX_FOLD = max(w.MAX_FOLD, B)
+        img_seeds = [seeds["image"][slots.index(b)] if b in slots else 1000 + b for b in range(B)]
+        src = ["seed:%d" % (seeds["c_src"][slots.index(b)] if b in slots else 2000 + b) for b in range(B)]
+        tgt = ["seed:%d" % (seeds["c_tgt"][slots.index(b)] if b in slots else 3000 + b) for b in range(B)]
+        images = torch.cat([torch.rand((1, 3, 256, 256), generator=torch.Generator().manual_seed(s)) for s in img_seeds], 0)
+        w.noise_source = _BlockNoise(seeds["noise"], slots, B)
+        z = None
+        with torch.no_grad():
+            x = images.cuda()
+            if mode == "batch16_coupled":
+                img = w.translate(x, src, tgt)
+                assert w.last_translate_coupled
+            else:
+                z_ens = w.encode(x, src)
+                img = w(z_ens, x, src, tgt)
+                z = z_ens[0].view(B, int(fx["white_box_steps"]) - skip, 4, 32, 32)[slots].cpu()
+        assert img.shape == (B, 3, 256, 256) and torch.isfinite(img).all()
+        ps = [gu.psnr(img[b:b + 1].cpu(), ref[i:i + 1]) for i, b in enumerate(slots)]
+        row = dict(psnr_db_by_triplet=ps, reference_cpu_seconds=float(fx["cpu_seconds"]), batch=B)
+        if z is not None:
+            zr, sl = torch.as_tensor(fx["z_sub"]), [int(s) for s in fx["z_sub_slots"]]
+            row["xT_maxabs"] = (z[:, 0] - zr[:, 0]).abs().max().item()
+            row["eps_rel_slots"] = [((z[:, s] - zr[:, i]).abs().max() / zr[:, i].abs().max()).item()
+                                    for i, s in enumerate(sl) if s > 0]
+            zn = torch.as_tensor(fx["z_norms"])
+            row["z_norm_rel"] = ((z.flatten(2).norm(dim=2) - zn).abs() / zn).max().item()
+            assert row["z_norm_rel"] < 2e-3 * FMT and max(row["eps_rel_slots"]) < 5e-2 * FMT, row
+        report.add("e2e/c3_ldm256_b16_" + mode, **row)
+        assert min(ps) >= PSNR_FLOOR, (mode, ps)
+        del img, x, images
+        torch.cuda.empty_cache()
