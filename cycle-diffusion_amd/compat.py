@@ -17,8 +17,6 @@ own loop, and the independent cross-check of those loops (tests/test_gpu_compat.
 import numpy as np
 import torch
 
-from . import _ffi  # noqa: F401  (the engine below is the only thing that computes)
-
 
 class _Posterior:
     """What encode_first_stage returns (ldm/modules/distributions/distributions.py:24-37): sample() / mode() of the diagonal
