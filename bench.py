@@ -696,7 +696,16 @@ def main():
                          "one launch set of %d steps, single stream, per-launch HIP events" % S,
                          "launches_per_step": n_launch / S, "kernel_ms_per_step": k_ms / S,
                          "algorithmic_tflop_per_step": k_flops / 1e12 / S,
-                         "whole_path_frac": ips * wl["flop_per_image"] / 1e12 / (world * peak)},
+                         "whole_path_frac": ips * wl["flop_per_image"] / 1e12 / (world * peak),
+                         # what that fraction prices against what: the 16-bit lines against the dense 16-bit MFMA peak; the
+                         # fp32 / fp32x3 lines mix three pipes (split products on the 16-bit cores at a third of their rate,
+                         # raw-input convs and attention on v_mfma_f32_32x32x2_f32 at 157 TFLOP/s, fp32 VALU norms), so their
+                         # fraction is an index against ONE of them, not a utilisation
+                         "whole_path_frac_basis": ("algorithmic FLOPs of the reference path / fp32 MFMA peak (157.3 TFLOP/s); "
+                                                   "attention and norms run on other pipes" if f32 else
+                                                   "algorithmic FLOPs of the reference path / (16-bit MFMA peak / 3): the split "
+                                                   "products' ceiling; raw-input convs and attention run on the fp32 MFMA pipe" if x3
+                                                   else "algorithmic FLOPs of the reference path / dense 16-bit MFMA peak")},
         }
         if sustained is not None:
             res["roofline"]["sustained_peak"] = sustained
