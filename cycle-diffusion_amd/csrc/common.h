@@ -185,6 +185,38 @@ __device__ inline float gelu_fast(float x) {
   return fmaxf(x, 0.0f) - poly * t * e * ax;
 }
 
+// Two / eight of them at a time for the GEGLU epilogues (conv_gemm.hip, lin_stream.hip), which are VALU-issue-bound: the
+// polynomial, the products and the final difference on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two
+// lanes' worth per issue slot) - 15 full-rate operations + 4 transcendentals per PAIR instead of 22 + 4. Same operations in
+// the same order as gelu_fast on each element: the same bits.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ inline f32x2 gelu_fast2(f32x2 x) {
+#pragma clang fp contract(off)
+  const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+  const f32x2 d = __builtin_elementwise_fma((f32x2){0.231641888f, 0.231641888f}, ax, (f32x2){1.0f, 1.0f});
+  const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  f32x2 poly = __builtin_elementwise_fma(t, (f32x2){0.5307027145f, 0.5307027145f}, (f32x2){-0.7265760135f, -0.7265760135f});
+  poly = __builtin_elementwise_fma(t, poly, (f32x2){0.7107068705f, 0.7107068705f});
+  poly = __builtin_elementwise_fma(t, poly, (f32x2){-0.142248368f, -0.142248368f});
+  poly = __builtin_elementwise_fma(t, poly, (f32x2){0.127414796f, 0.127414796f});
+  const f32x2 xx = x * x;
+  const f32x2 arg = -xx * (f32x2){0.72134752f, 0.72134752f};
+  const f32x2 e = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+  const f32x2 mx = {fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
+  return mx - poly * t * e * ax;
+}
+// out[e] = val[e] * gelu(gate[e]), e = 0 .. 7
+__device__ inline void mul_gelu8(const float* val, const float* gate, float* out) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 g = {gate[2 * i], gate[2 * i + 1]}, v = {val[2 * i], val[2 * i + 1]};
+    const f32x2 r = v * gelu_fast2(g);
+    out[2 * i] = r[0];
+    out[2 * i + 1] = r[1];
+  }
+}
+
 // ---- error handling: no exception crosses the C ABI -----------------------------------------
 struct Error : public std::runtime_error {
   explicit Error(const std::string& m) : std::runtime_error(m) {}

@@ -57,13 +57,20 @@ struct TileCfg {
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   static constexpr int EPI_BYTES = NW * TM * EPI_LD * 4;
   static constexpr int LDS_BYTES = STAGE_BYTES * NSTAGE > EPI_BYTES ? STAGE_BYTES * NSTAGE : EPI_BYTES;
+  // behind the ring: the tile's bias row [BN] and the time-embedding rows of its BM / 32 row blocks [BM / 32][BN] (fp32), filled
+  // by the prologue's first DMA copies (1 KB per wave-wide copy) for the fast epilogue
+  static constexpr int TAB_BIAS_I = (BN / 4 + 63) / 64;              // wave-wide copies: the bias row
+  static constexpr int TAB_RV_I = ((BM / 32) * (BN / 4) + 63) / 64;  // ... the embedding rows
+  // (256x64 with a 4-deep ring fills the 160 KB by itself: no tables, generic epilogue - the shipped table never picks it)
+  static constexpr bool HAS_TAB = LDS_BYTES + (TAB_BIAS_I + TAB_RV_I) * 1024 <= 160 * 1024;
+  static constexpr int TAB_BYTES = HAS_TAB ? (TAB_BIAS_I + TAB_RV_I) * 1024 : 0;
   static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");
   static_assert(A_IPW >= 1 && B_IPW >= 1, "tile too small for the wave count");
   static_assert(A_IPW * RPI * NW == BM && B_IPW * RPI * NW == BN, "tile rows must split evenly over waves");
   static_assert(MT >= 1 && NT >= 1, "wave tile");
   static_assert(NSTAGE >= 2 && NSTAGE <= 8, "ring depth");
   static_assert((NSTAGE - 2) * LPT <= 63, "vmcnt field");
-  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+  static_assert(LDS_BYTES + TAB_BYTES <= 160 * 1024, "LDS");
 };
 
 template <int N>
@@ -93,6 +100,14 @@ __device__ __forceinline__ unsigned long long probe_realtime() {
 #define CD_PROBE_ONLY(...)
 #endif
 
+// the straight-line epilogue (16-bit output, no activation, 16-byte aligned rows): see the kernel's epilogue
+__device__ __forceinline__ bool fast_epilogue(const ConvGemmParams& p) {
+  return p.act == ACT_NONE && !p.out_f32 && !p.resid_f32 && (p.N & 7) == 0 && (p.out_ld & 7) == 0 &&
+         (((uintptr_t)p.out | (uintptr_t)p.resid | (uintptr_t)p.rowvec) & 15) == 0 && (p.o_bs & 7) == 0 &&
+         (!p.resid || (p.resid_ld & 7) == 0) &&
+         (!p.rowvec || ((p.rowvec_ld & 3) == 0 && (p.rows_per_vec >= p.M || (p.rows_per_vec & 31) == 0)));
+}
+
 // CHM: channel-major K order (compile-time: the tap-major instantiation carries none of its state)
 template <int BM, int BN, int BK, int WM, int WN, int NSTAGE, bool CHM = false>
 // (4-wave workgroups with 32-deep K steps are the two-per-CU configurations: 2 waves per SIMD, so at most 256 registers)
@@ -111,7 +126,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
   const unsigned long long pr_rt0 = probe_realtime();
   unsigned long long pr_t0 = probe_time(), pr_prol = 0, pr_first = 0, pr_wait = 0, pr_comp = 0, pr_maxw = 0, pr_loop = 0,
                      pr_drain = 0, pr_stage = 0, pr_rows = 0, pr_issued = 0, pr_last = 0;
-  unsigned* pr_log = (unsigned*)(smem + T::LDS_BYTES) + wave * 64;  // (arrive, pass) of the first 32 K steps
+  unsigned* pr_log = (unsigned*)(smem + T::LDS_BYTES + T::TAB_BYTES) + wave * 64;  // (arrive, pass) of the first 32 K steps
   if (lane < 64) pr_log[lane] = 0;)
 
   // ---- block -> tile, XCD-aware (block b runs on XCD b%8; give each XCD a contiguous tile range
@@ -349,8 +364,44 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
 #pragma unroll
     for (int l = 0; l < LPT; ++l) issue(l, s);
   }
+  // ---- bias / time-embedding tables of the fast epilogue (T::TAB_BYTES behind the ring), by DMA like the operands. Issued AFTER
+  // the ring's first tiles so that their set-up (three more kernel-argument fetches, two descriptors) runs while tile kt0 is in
+  // flight, and the SAME NUMBER of copies from every wave on every path, so the counted waits below stay exact: a wave whose
+  // share runs past the last copy repeats an earlier one (same bytes), a launch without the fast epilogue copies through
+  // empty descriptors (zeros). The K loop's drain (vmcnt(0) + barrier) publishes the tables to the epilogue.
+  constexpr int TAB_N = T::TAB_BIAS_I + T::TAB_RV_I;                  // wave-wide 1 KB copies in all
+  constexpr int TABI = T::HAS_TAB ? (TAB_N + NW - 1) / NW : 0;        // ... per wave
+  if constexpr (TABI > 0) {
+    const bool fe = fast_epilogue(p);
+    char* tab = smem + T::LDS_BYTES;
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((fe && p.bias) ? (const void*)p.bias : (const void*)p.wgt), 0, (fe && p.bias) ? p.N * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((fe && p.rowvec) ? (const void*)p.rowvec : (const void*)p.wgt), 0, (fe && p.rowvec) ? kRange : 0, 0x00020000);
+    const unsigned rpv = (unsigned)p.rows_per_vec;
+    const bool rpv_pow2 = (rpv & (rpv - 1)) == 0;  // image sizes are powers of two on every reference network: a shift
+    const int rpv_sh = 31 - __builtin_clz(rpv | 1u);
+#pragma unroll
+    for (int i = 0; i < TABI; ++i) {
+      int j = i * NW + wave;  // (uniform) copy number: bias copies first
+      if (j >= TAB_N) j -= TAB_N;
+      if (j < T::TAB_BIAS_I) {
+        const int c4 = j * 64 + lane;  // 16-byte chunk of the bias row (beyond BN: the next tile's columns or zeros, unused)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lptr_t)(tab + j * 1024), 16, (unsigned)((n0 + c4 * 4) * 4), 0, 0, 0);
+      } else {
+        const int c = (j - T::TAB_BIAS_I) * 64 + lane;  // chunk c = (row block, 16-byte chunk of its embedding row)
+        const int blk = c / (BN / 4), c4 = c - blk * (BN / 4);
+        const int m = m0 + blk * 32, nn = n0 + c4 * 4;
+        int rvi = 0;
+        if (p.rows_per_vec < p.M) rvi = rpv_pow2 ? (int)((unsigned)m >> rpv_sh) : m / p.rows_per_vec;
+        const unsigned vo = (m < p.M && nn < p.N) ? (unsigned)((rvi * p.rowvec_ld + nn) * 4) : kInvalid;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (lptr_t)(tab + j * 1024), 16, vo, 0, 0, 0);
+      }
+    }
+  }
   CD_PROBE_ONLY(pr_prol = probe_time(); pr_last = pr_prol;)
-  wait_vmcnt_barrier<(NSTAGE - 1) * LPT>();  // tile kt0 has landed everywhere
+  static_assert((NSTAGE - 1) * LPT + TABI <= 63, "vmcnt field");
+  wait_vmcnt_barrier<(NSTAGE - 1) * LPT + TABI>();  // tile kt0 has landed everywhere (younger: the other tiles, the table copies)
   CD_PROBE_ONLY(pr_first = probe_time(); pr_last = pr_first;)
 
   bf16x8 af[KS][MT], bfr[KS][NT];
@@ -490,286 +541,392 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
   float* E = (float*)smem + wave * (TM * T::EPI_LD);
   const bool geglu = (p.act == ACT_GEGLU);
   char* outp = (char*)p.out + (int64_t)zb * p.o_bs * (p.out_f32 ? 4 : 2);
-#pragma unroll
-  for (int jc = 0; jc < NT; jc += CJ) {
-    const int cj = (NT - jc) < CJ ? (NT - jc) : CJ;  // blocks in this chunk (compile-time after unrolling)
-    const int cw = cj * 32;
-    CD_PROBE_ONLY(const unsigned long long pr_c0 = probe_time();)
-    __builtin_amdgcn_wave_barrier();
+  if (p.alpha != 1.0f) {  // (uniform) the attention-score GEMMs of the first stage; everything else leaves its sums as they are
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < CJ; ++j)
-        if (j < cj) {
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-            E[row * T::EPI_LD + j * 32 + frow] = acc[i][jc + j][r] * p.alpha;
-          }
-        }
-    __builtin_amdgcn_wave_barrier();
-    CD_PROBE_ONLY(const unsigned long long pr_c1 = probe_time(); pr_stage += pr_c1 - pr_c0;)
-    // GEGLU: packed columns come in blocks of 64 = [32 value | 32 gate] (k_pack_rows) = one chunk; only the value
-    // half produces output, at column (n/64)*32 + n%32.
-    const int vpr = geglu ? 4 : (cw / 8);  // 8-wide vectors per row handled
-    const int rpp = 64 / vpr;              // rows per pass
-    const int vr = lane_ep / vpr, vc = lane_ep % vpr;
-    // column-only quantities are the same for every row this lane handles: hoist them out of the row loop
-    const int col = vc * 8;                            // column inside the chunk
-    const int n = n0 + wn * TN + jc * 32 + col;        // packed column
-    const int nvalid = (p.N - n) < 8 ? (p.N - n) : 8;
-    float bias_v[8], bias_g[8];
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= p.alpha;
+  }
+  if (T::HAS_TAB && fast_epilogue(p)) {
+    // ---- the common flavour (16-bit output, no activation: every ResBlock / transformer projection of the U-Nets and first
+    // stages): one 32-row block at a time with all its LDS reads issued before any arithmetic; GroupNorm statistics of the
+    // block from per-lane partial sums over its passes, transposed through the LDS rows just consumed, column sums by the lane
+    // that owns the column -> two dense 256-byte stores (round 4). Round 6 (profiles/r6_conv_tile_phase_timing.txt: the row
+    // passes are VALU-issue-bound at ~45 operations per 8-value vector, and a tile with a residual spends 6 us of its 37
+    // waiting for it) made it STRAIGHT-LINE code whose only vector-memory operations are the residual loads and the stores:
+    //   * all global traffic goes through buffer descriptors that start at the wave tile's first row and END AT ITS LAST VALID
+    //     ROW (statistics: row block): a row beyond M or a column vector beyond N (offset bit 31) is dropped / read as zeros by
+    //     the bounds check - no per-row compare, no exec-mask juggling, no 64-bit address arithmetic, one v_add_u32 per vector;
+    //   * bias and time-embedding rows come from the LDS tables the prologue filled by DMA (T::TAB_BYTES);
+    //   * the residual is fetched ONE 32-ROW BLOCK AHEAD: vector-memory operations return in order on gfx9, so a load issued
+    //     behind the previous block's stores waits for their acknowledgements. With no branch between issue and use (the
+    //     loads are issued even without a residual: an empty descriptor returns zeros without touching memory) the compiler's
+    //     counted s_waitcnt vmcnt leaves the younger loads and the previous block's stores in flight.
+    // (16-byte vector accesses: row strides AND base pointers must be multiples of 16 bytes - the batch strides are element
+    // counts that keep the alignment when the leading dimensions do; odd shapes take the generic loop)
+    constexpr int LD = T::EPI_LD, NRB = TM / 32;  // 32-row blocks per chunk
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4e;
+    const int mw = m0 + wm * TM;  // first row of the wave tile
+    const bool has_res = p.resid != nullptr;
+    // (the descriptor words go through v_readfirstlane: behind the split-K fix-up's data-dependent return the compiler no longer
+    // treats them as wave-uniform and would wrap every buffer operation in a waterfall loop)
+    auto uniform_rsrc = [](const void* base, int bytes) __attribute__((always_inline)) {
+      const uint64_t u = (uint64_t)base;
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+    };
+    int rows_ok = p.M - mw;
+    rows_ok = rows_ok < 0 ? 0 : (rows_ok > TM ? TM : rows_ok);
+    const int nblk = (p.M + 31) >> 5;
+    int blk_ok = nblk - (mw >> 5);
+    blk_ok = blk_ok < 0 ? 0 : (blk_ok > NRB ? NRB : blk_ok);
+    const __amdgpu_buffer_rsrc_t rs_o = uniform_rsrc(outp + (int64_t)mw * p.out_ld * 2, rows_ok * p.out_ld * 2);
+    const __amdgpu_buffer_rsrc_t rs_r =
+        uniform_rsrc(has_res ? (const void*)(p.resid + (int64_t)zb * p.o_bs + (int64_t)mw * p.resid_ld) : (const void*)outp,
+                     has_res ? rows_ok * p.resid_ld * 2 : 0);
+    const __amdgpu_buffer_rsrc_t rs_s =
+        uniform_rsrc(p.stats ? (const void*)(p.stats + ((int64_t)zb * nblk + (mw >> 5)) * 2 * p.N) : (const void*)outp,
+                     p.stats ? blk_ok * 2 * p.N * 4 : 0);
+    const float* TB = (const float*)(smem + T::LDS_BYTES) + wn * TN;              // bias row of the tile
+    const float* TR = (const float*)(smem + T::LDS_BYTES) + T::TAB_BIAS_I * 256 + (wm * NRB) * BN + wn * TN;  // embedding rows
+    // residual vectors of 32-row block `rbx` of the chunk starting at MFMA column block `jcx` (the chunk's own lane geometry)
+    constexpr bool PIPE = NW <= 8;  // (16-wave tiles live on 128 registers: they fetch the residual at the top of its own block)
+    u32x4e rq[PIPE ? 2 : 1][4];
+    auto resid_issue = [&](int jcx, int rbx, u32x4e (&dst)[4]) __attribute__((always_inline)) {
+      const int cwx = ((NT - jcx) < CJ ? (NT - jcx) : CJ) * 32, vprx = cwx / 8, rppx = 64 / vprx, npx = 32 / rppx;
+      const int nx = n0 + wn * TN + jcx * 32 + (lane_ep % vprx) * 8;
+      const unsigned vo = nx < p.N ? (unsigned)(((rbx * 32 + lane_ep / vprx) * p.resid_ld + nx) * 2) : kInvalid;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      bias_v[e] = (p.bias && e < nvalid) ? p.bias[n + e] : 0.0f;
-      bias_g[e] = (geglu && p.bias) ? p.bias[n + 32 + e] : 0.0f;
-    }
-    // optional fused GroupNorm statistics: per-channel sum / sum-of-squares of the FINAL values over each
-    // 32-row block of the output, written to stats[rowblock][2][N] (no atomics; the 32-row granularity is
-    // independent of the tile configuration and of the batch size)
-    float ssum[8], ssq[8];
+      for (int ps = 0; ps < 4; ++ps)
+        if (ps < npx) dst[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, vo + (unsigned)(ps * rppx * p.resid_ld * 2), 0, 0);
+    };
+    if constexpr (PIPE) resid_issue(0, 0, rq[0]);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
-    // ---- the common flavour (16-bit output, no activation: every ResBlock / transformer projection of the U-Nets and
-    // first stages): one 32-row block at a time with all its LDS reads and residual loads issued before any arithmetic
-    // (round 4 phase timing, profiles/r4_conv_tile_phase_timing.txt: the one-pass-at-a-time loop below spent 0.8 k cycles per
-    // 8-row pass on exposed LDS / L2 latency, and the statistics another 0.45 k on a 48-shuffle butterfly plus sixteen
-    // 8-lane stores). GroupNorm statistics of the block: per-lane partial sums over the block's passes, transposed through
-    // the LDS rows just consumed, column sums by the lane that owns the column -> two dense 256-byte stores.
-    // (16-byte vector accesses below: row strides AND base pointers must be multiples of 16 bytes - the batch strides are
-    // element counts that keep the alignment when the leading dimensions do; odd shapes take the generic loop)
-    const bool fast = !geglu && !p.out_f32 && !p.resid_f32 && p.act == ACT_NONE && (p.N & 7) == 0 && (p.out_ld & 7) == 0 &&
-                      (((uintptr_t)p.out | (uintptr_t)p.resid | (uintptr_t)p.rowvec) & 15) == 0 && (p.o_bs & 7) == 0 &&
-                      (!p.resid || (p.resid_ld & 7) == 0) &&
-                      (!p.rowvec || ((p.rowvec_ld & 3) == 0 && (p.rows_per_vec >= p.M || (p.rows_per_vec & 31) == 0)));
-    if (fast) {
-      constexpr int LD = T::EPI_LD;
-      const int RPP = 64 / (cw / 8), NP = 32 / RPP;  // rows per pass, passes per 32-row block (compile-time: cw is)
-      const bool colok = n < p.N;
-      bf16_t* const ocol = (bf16_t*)outp + n;
-      const bf16_t* const rcol = p.resid ? p.resid + (int64_t)zb * p.o_bs + n : nullptr;
+    for (int jc = 0; jc < NT; jc += CJ) {
+      const int cj = (NT - jc) < CJ ? (NT - jc) : CJ;  // blocks in this chunk (compile-time after unrolling)
+      const int cw = cj * 32;
+      const int RPP = 64 / (cw / 8), NP = 32 / RPP;    // rows per pass, passes per 32-row block
+      const int vr = lane_ep / (cw / 8), col = (lane_ep % (cw / 8)) * 8;  // row within a pass, column inside the chunk
+      const int n = n0 + wn * TN + jc * 32 + col;
+      CD_PROBE_ONLY(const unsigned long long pr_c0 = probe_time();)
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int rb = 0; rb < TM / 32; ++rb) {
-        const int mb = m0 + wm * TM + rb * 32;  // first row of the block
-        if (mb < p.M) {                         // (uniform) ragged M: whole blocks beyond the last row do nothing
-          f32x4 lo[4], hi[4];
-          uint4 rr[4];
-          bool ok[4];
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int ps = 0; ps < 4; ++ps)
-            if (ps < NP) {
-              const float* er = E + (rb * 32 + ps * RPP + vr) * LD + col;
-              lo[ps] = *(const f32x4*)er;
-              hi[ps] = *(const f32x4*)(er + 4);
-            }
+        for (int j = 0; j < CJ; ++j)
+          if (j < cj) {
 #pragma unroll
-          for (int ps = 0; ps < 4; ++ps)
-            if (ps < NP) {
-              const int m = mb + ps * RPP + vr;
-              ok[ps] = colok && m < p.M;
-              rr[ps] = (uint4){0u, 0u, 0u, 0u};
-              if (rcol && ok[ps]) rr[ps] = *(const uint4*)(rcol + (int64_t)m * p.resid_ld);
-            }
-          float add[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) add[e] = bias_v[e];
-          if (p.rowvec && colok) {  // one time-embedding row per image; a 32-row block lies inside one image
-            const int rvi = (p.rows_per_vec >= p.M) ? 0 : mb / p.rows_per_vec;
-            const float* rv = p.rowvec + (int64_t)rvi * p.rowvec_ld + n;
-            const f32x4 r0v = *(const f32x4*)rv, r1v = *(const f32x4*)(rv + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { add[e] += r0v[e]; add[4 + e] += r1v[e]; }
-          }
-#pragma unroll
-          for (int ps = 0; ps < 4; ++ps)
-            if (ps < NP) {
-              float v[8], rf[8];
-              unpack8(rr[ps], rf);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { v[e] = lo[ps][e] + add[e]; v[4 + e] = hi[ps][e] + add[4 + e]; }
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += rf[e];
-              if (ok[ps]) {
-                CD_PROBE_ONLY(if (!(p.dbg & 1)))
-                *(uint4*)(ocol + (int64_t)(mb + ps * RPP + vr) * p.out_ld) = pack8(v);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
-              }
-            }
-          if (p.stats) {
-            float* S = E + rb * 32 * LD;  // the block's rows are in registers: 2 x 512 floats of them as scratch
-            __builtin_amdgcn_wave_barrier();
-            *(f32x4*)(S + vr * cw + col) = (f32x4){ssum[0], ssum[1], ssum[2], ssum[3]};
-            *(f32x4*)(S + vr * cw + col + 4) = (f32x4){ssum[4], ssum[5], ssum[6], ssum[7]};
-            *(f32x4*)(S + 512 + vr * cw + col) = (f32x4){ssq[0], ssq[1], ssq[2], ssq[3]};
-            *(f32x4*)(S + 512 + vr * cw + col + 4) = (f32x4){ssq[4], ssq[5], ssq[6], ssq[7]};
-            __builtin_amdgcn_wave_barrier();
-            const int nc0 = n0 + wn * TN + jc * 32;  // first column of the chunk
-            float* sp = p.stats + ((int64_t)zb * ((p.M + 31) >> 5) + (mb >> 5)) * 2 * p.N + nc0;
-            if (cw == 64) {
-              float s = 0.f, q = 0.f;
-#pragma unroll
-              for (int k = 0; k < 8; ++k) { s += S[k * 64 + lane_ep]; q += S[512 + k * 64 + lane_ep]; }
-              if (nc0 + lane_ep < p.N) { sp[lane_ep] = s; sp[p.N + lane_ep] = q; }
-            } else {  // 32-column chunk: lanes 0-31 own the sums, 32-63 the sums of squares
-              const int arr = lane_ep >> 5, c = lane_ep & 31;
-              float s = 0.f;
-#pragma unroll
-              for (int k = 0; k < 16; ++k) s += S[arr * 512 + k * 32 + c];
-              if (nc0 + c < p.N) sp[arr * p.N + c] = s;
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
-          }
-        }
-      }
-      CD_PROBE_ONLY(pr_rows += probe_time() - pr_c1;)
-      continue;
-    }
-    // GEGLU (attention.py:37-44: value * gelu(gate)), the feed-forward input projection of every transformer block: the same
-    // block form. A 64-column chunk = [32 value | 32 gate] columns; 4 lanes cover a row's 32 outputs, 16 rows per pass.
-    if (geglu && cw == 64 && !p.out_f32 && !p.resid && !p.stats && !p.rowvec && (p.N & 63) == 0 && (p.out_ld & 7) == 0) {
-      constexpr int LD = T::EPI_LD;
-      bf16_t* const ocol = (bf16_t*)outp + (n / 64) * 32 + (n % 64);
-#pragma unroll
-      for (int rb = 0; rb < TM / 32; ++rb) {
-        const int mb = m0 + wm * TM + rb * 32;
-        if (mb < p.M) {
-          f32x4 vl[2], vh[2], gl[2], gh[2];
-#pragma unroll
-          for (int ps = 0; ps < 2; ++ps) {
-            const float* er = E + (rb * 32 + ps * 16 + vr) * LD + col;
-            vl[ps] = *(const f32x4*)er;        vh[ps] = *(const f32x4*)(er + 4);
-            gl[ps] = *(const f32x4*)(er + 32); gh[ps] = *(const f32x4*)(er + 36);
-          }
-#pragma unroll
-          for (int ps = 0; ps < 2; ++ps) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[e] = (vl[ps][e] + bias_v[e]) * gelu_fast(gl[ps][e] + bias_g[e]);
-              v[4 + e] = (vh[ps][e] + bias_v[4 + e]) * gelu_fast(gh[ps][e] + bias_g[4 + e]);
-            }
-            const int m = mb + ps * 16 + vr;
-            if (m < p.M && n < p.N) {
-              CD_PROBE_ONLY(if (!(p.dbg & 1)))
-              *(uint4*)(ocol + (int64_t)m * p.out_ld) = pack8(v);
+            for (int r = 0; r < 16; ++r) {
+              const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+              E[row * LD + j * 32 + frow] = acc[i][jc + j][r];
             }
           }
-        }
-      }
-      CD_PROBE_ONLY(pr_rows += probe_time() - pr_c1;)
-      continue;
-    }
-    for (int r0 = 0; r0 < TM; r0 += rpp) {
-      const int row = r0 + vr;
-      const int m = m0 + wm * TM + row;
-      if (row < TM && m < p.M && n < p.N) {
-      float v[8];
-      {
-        const f32x4 lo = *(const f32x4*)(E + row * T::EPI_LD + col);
-        const f32x4 hi = *(const f32x4*)(E + row * T::EPI_LD + col + 4);
-        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-      }
+      __builtin_amdgcn_wave_barrier();
+      CD_PROBE_ONLY(const unsigned long long pr_c1 = probe_time(); pr_stage += pr_c1 - pr_c0;)
+      const f32x4 b0 = *(const f32x4*)(TB + jc * 32 + col), b1 = *(const f32x4*)(TB + jc * 32 + col + 4);
+      const unsigned vo_out = n < p.N ? (unsigned)((vr * p.out_ld + n) * 2) : kInvalid;  // + the pass's row offset
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += bias_v[e];
-      int on = n;  // output column
-      if (geglu) {
-        float gt[8];
-        const f32x4 lo = *(const f32x4*)(E + row * T::EPI_LD + col + 32);
-        const f32x4 hi = *(const f32x4*)(E + row * T::EPI_LD + col + 36);
-        gt[0] = lo[0]; gt[1] = lo[1]; gt[2] = lo[2]; gt[3] = lo[3];
-        gt[4] = hi[0]; gt[5] = hi[1]; gt[6] = hi[2]; gt[7] = hi[3];
+      for (int rb = 0; rb < NRB; ++rb) {
+        const int kb = (jc / CJ) * NRB + rb;  // running block number: the residual registers alternate
+        const int mb = mw + rb * 32;          // first row of the block
+        if constexpr (!PIPE) resid_issue(jc, rb, rq[0]);  // the NEXT block's residual, ahead of this block's stores
+        else if (rb + 1 < NRB) resid_issue(jc, rb + 1, rq[(kb + 1) & 1]);
+        else if (jc + CJ < NT) resid_issue(jc + CJ, 0, rq[(kb + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 lo[4], hi[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float gg = gt[e] + bias_g[e];
-          v[e] = v[e] * gelu_fast(gg);
-        }
-        on = (n / 64) * 32 + (n % 64);
-      } else {
-        if (p.rowvec) {
-          const int rvi = (p.rows_per_vec >= p.M) ? 0 : m / p.rows_per_vec;  // shared timestep: one vector
-          const float* rv = p.rowvec + (int64_t)rvi * p.rowvec_ld + n;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += rv[e];
-        }
-        if (p.act == ACT_SILU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-        } else if (p.act == ACT_GELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
-        } else if (p.act == ACT_QGELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
-        }
-      }
-      if (p.resid && p.resid_f32) {
-        const float* rp = (const float*)p.resid + (int64_t)zb * p.o_bs + (int64_t)m * p.resid_ld + on;
-        if (nvalid == 8 && ((p.resid_ld & 3) == 0)) {
-          const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += rp[e];
-        }
-      } else if (p.resid) {
-        const bf16_t* rp = p.resid + (int64_t)zb * p.o_bs + (int64_t)m * p.resid_ld + on;
-        if (nvalid == 8 && ((p.resid_ld & 7) == 0)) {
-          float rr[8];
-          unpack8(*(const uint4*)rp, rr);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rr[e];
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += bf2f(rp[e]);
-        }
-      }
-      CD_PROBE_ONLY(if (!(p.dbg & 1)))
-      if (p.out_f32) {
-        float* op = (float*)outp + (int64_t)m * p.out_ld + on;
-        if (nvalid == 8 && ((p.out_ld & 3) == 0)) {
-          *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
-          *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (e < nvalid) op[e] = v[e];
-        }
-      } else {
-        bf16_t* op = (bf16_t*)outp + (int64_t)m * p.out_ld + on;
-        if (nvalid == 8 && ((p.out_ld & 7) == 0)) {
-          *(uint4*)op = pack8(v);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (e < nvalid) op[e] = f2bf(v[e]);
-        }
-      }
-      CD_PROBE_ONLY(if (p.dbg & 1) { if (v[0] == 1.2345e-33f) ((float*)outp)[0] = v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7]; })
-      if (p.stats) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
-      }
-      }  // valid row
-      if (p.stats && ((r0 + rpp) & 31) == 0) {
-        // end of a 32-row block: fold the lanes that share this column vector (same vc, different vr)
-        for (int o = vpr; o < 64; o <<= 1) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { ssum[e] += __shfl_xor(ssum[e], o); ssq[e] += __shfl_xor(ssq[e], o); }
-        }
-        const int rb = (m0 + wm * TM + r0 + rpp - 32) >> 5;
-        if (vr == 0 && n < p.N && (rb << 5) < p.M) {
-          float* sp = p.stats + ((int64_t)zb * ((p.M + 31) >> 5) + rb) * 2 * p.N + n;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (e < nvalid) { sp[e] = ssum[e]; sp[p.N + e] = ssq[e]; }
-        }
+        for (int ps = 0; ps < 4; ++ps)
+          if (ps < NP) {
+            const float* er = E + (rb * 32 + ps * RPP + vr) * LD + col;
+            lo[ps] = *(const f32x4*)er;
+            hi[ps] = *(const f32x4*)(er + 4);
+          }
+        const f32x4 a0 = b0 + *(const f32x4*)(TR + rb * BN + jc * 32 + col);  // one embedding row per image; a block lies inside one
+        const f32x4 a1 = b1 + *(const f32x4*)(TR + rb * BN + jc * 32 + col + 4);
+        // (tiles of 8 waves keep the block's 4 x 8 values for the statistics, so that layers without statistics pay nothing for
+        // them; the 16-wave tiles live on 128 registers and accumulate pass by pass)
+        constexpr bool KEEP = NW <= 8;
+        float v[KEEP ? 4 : 1][8];
+        float ssum[8], ssq[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+        const unsigned vo_blk = vo_out + (unsigned)(rb * 32 * p.out_ld * 2);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps)
+          if (ps < NP) {
+            float* vp = v[KEEP ? ps : 0];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vp[e] = lo[ps][e] + a0[e]; vp[4 + e] = hi[ps][e] + a1[e]; }
+            if (has_res) {
+              float rf[8];
+              const u32x4e w = rq[PIPE ? (kb & 1) : 0][ps];
+              unpack8(make_uint4(w[0], w[1], w[2], w[3]), rf);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) vp[e] += rf[e];
+            }
+            const uint4 pk = pack8(vp);
+            CD_PROBE_ONLY(if (!(p.dbg & 1)))
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4e){pk.x, pk.y, pk.z, pk.w}, rs_o,
+                                                   vo_blk + (unsigned)(ps * RPP * p.out_ld * 2), 0, 0);
+            if constexpr (!KEEP) {
+              const float on = (mb + ps * RPP + vr) < p.M ? 1.0f : 0.0f;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { const float x = on * vp[e]; ssum[e] += x; ssq[e] += x * x; }
+            }
+          }
+        // fused GroupNorm statistics: per-channel sum / sum of squares of the FINAL values over each 32-row block of the output,
+        // written to stats[rowblock][2][N] (no atomics; the 32-row granularity is independent of the tile configuration and of
+        // the batch size)
+        float s_sum = 0.f, s_sq = 0.f;
+        if (p.stats) {
+          if constexpr (KEEP) {
+            if (mb + 32 <= p.M) {  // (uniform) every row of the block exists
+#pragma unroll
+              for (int ps = 0; ps < 4; ++ps)
+                if (ps < NP) {
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) { ssum[e] += v[ps][e]; ssq[e] += v[ps][e] * v[ps][e]; }
+                }
+            } else {
+#pragma unroll
+              for (int ps = 0; ps < 4; ++ps)
+                if (ps < NP) {
+                  const float on = (mb + ps * RPP + vr) < p.M ? 1.0f : 0.0f;
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) { const float x = on * v[ps][e]; ssum[e] += x; ssq[e] += x * x; }
+                }
+            }
+          }
+          float* S = E + rb * 32 * LD;  // the block's rows are in registers: 2 x 512 floats of them as scratch
+          __builtin_amdgcn_wave_barrier();
+          *(f32x4*)(S + vr * cw + col) = (f32x4){ssum[0], ssum[1], ssum[2], ssum[3]};
+          *(f32x4*)(S + vr * cw + col + 4) = (f32x4){ssum[4], ssum[5], ssum[6], ssum[7]};
+          *(f32x4*)(S + 512 + vr * cw + col) = (f32x4){ssq[0], ssq[1], ssq[2], ssq[3]};
+          *(f32x4*)(S + 512 + vr * cw + col + 4) = (f32x4){ssq[4], ssq[5], ssq[6], ssq[7]};
+          __builtin_amdgcn_wave_barrier();
+          if (cw == 64) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s_sum += S[k * 64 + lane_ep]; s_sq += S[512 + k * 64 + lane_ep]; }
+          } else {  // 32-column chunk: lanes 0-31 own the sums, 32-63 the sums of squares
+            const int arr = lane_ep >> 5, c = lane_ep & 31;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s_sum += S[arr * 512 + k * 32 + c];
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        {  // (issued without statistics too - an empty descriptor drops them - so that every path carries the same store count)
+          const int nc0 = n0 + wn * TN + jc * 32;  // first column of the chunk
+          if (cw == 64) {
+            const unsigned so = nc0 + lane_ep < p.N ? (unsigned)((rb * 2 * p.N + nc0 + lane_ep) * 4) : kInvalid;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s_sum), rs_s, so, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s_sq), rs_s, so + (unsigned)(p.N * 4), 0, 0);
+          } else {
+            const int arr = lane_ep >> 5, c = lane_ep & 31;
+            const unsigned so = nc0 + c < p.N ? (unsigned)((rb * 2 * p.N + arr * p.N + nc0 + c) * 4) : kInvalid;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s_sum), rs_s, so, 0, 0);
+          }
+        }
       }
+      CD_PROBE_ONLY(pr_rows += probe_time() - pr_c1;)
     }
-    CD_PROBE_ONLY(pr_rows += probe_time() - pr_c1;)
+  } else {
+#pragma unroll
+    for (int jc = 0; jc < NT; jc += CJ) {
+      const int cj = (NT - jc) < CJ ? (NT - jc) : CJ;  // blocks in this chunk (compile-time after unrolling)
+      const int cw = cj * 32;
+      CD_PROBE_ONLY(const unsigned long long pr_c0 = probe_time();)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < CJ; ++j)
+          if (j < cj) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+              E[row * T::EPI_LD + j * 32 + frow] = acc[i][jc + j][r];
+            }
+          }
+      __builtin_amdgcn_wave_barrier();
+      CD_PROBE_ONLY(const unsigned long long pr_c1 = probe_time(); pr_stage += pr_c1 - pr_c0;)
+      // GEGLU: packed columns come in blocks of 64 = [32 value | 32 gate] (k_pack_rows) = one chunk; only the value
+      // half produces output, at column (n/64)*32 + n%32.
+      const int vpr = geglu ? 4 : (cw / 8);  // 8-wide vectors per row handled
+      const int rpp = 64 / vpr;              // rows per pass
+      int lane_g = lane_ep;  // (opaque again: none of this path's per-lane pointers is formed ahead of the staging writes)
+      asm volatile("" : "+v"(lane_g));
+      const int vr = lane_g / vpr, vc = lane_g % vpr;
+      // column-only quantities are the same for every row this lane handles: hoist them out of the row loop
+      const int col = vc * 8;                            // column inside the chunk
+      const int n = n0 + wn * TN + jc * 32 + col;        // packed column
+      const int nvalid = (p.N - n) < 8 ? (p.N - n) : 8;
+      float bias_v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bias_v[e] = (p.bias && e < nvalid) ? p.bias[n + e] : 0.0f;
+      // optional fused GroupNorm statistics: per-channel sum / sum-of-squares of the FINAL values over each
+      // 32-row block of the output, written to stats[rowblock][2][N] (no atomics; the 32-row granularity is
+      // independent of the tile configuration and of the batch size)
+      float ssum[8], ssq[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+      // GEGLU (attention.py:37-44: value * gelu(gate)), the feed-forward input projection of every transformer block: the same
+      // block form. A 64-column chunk = [32 value | 32 gate] columns; 4 lanes cover a row's 32 outputs, 16 rows per pass.
+      if (geglu && cw == 64 && !p.out_f32 && !p.resid && !p.stats && !p.rowvec && (p.N & 63) == 0 && (p.out_ld & 7) == 0) {
+        constexpr int LD = T::EPI_LD;
+        bf16_t* const ocol = (bf16_t*)outp + (n / 64) * 32 + (n % 64);
+        float bias_g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias_g[e] = p.bias ? p.bias[n + 32 + e] : 0.0f;
+#pragma unroll
+        for (int rb = 0; rb < TM / 32; ++rb) {
+          const int mb = m0 + wm * TM + rb * 32;
+          if (mb < p.M) {
+            f32x4 vl[2], vh[2], gl[2], gh[2];
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+              const float* er = E + (rb * 32 + ps * 16 + vr) * LD + col;
+              vl[ps] = *(const f32x4*)er;        vh[ps] = *(const f32x4*)(er + 4);
+              gl[ps] = *(const f32x4*)(er + 32); gh[ps] = *(const f32x4*)(er + 36);
+            }
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+              float v[8], va[8], ga[8];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                va[e] = vl[ps][e] + bias_v[e]; va[4 + e] = vh[ps][e] + bias_v[4 + e];
+                ga[e] = gl[ps][e] + bias_g[e]; ga[4 + e] = gh[ps][e] + bias_g[4 + e];
+              }
+              mul_gelu8(va, ga, v);
+              const int m = mb + ps * 16 + vr;
+              if (m < p.M && n < p.N) {
+                CD_PROBE_ONLY(if (!(p.dbg & 1)))
+                *(uint4*)(ocol + (int64_t)m * p.out_ld) = pack8(v);
+              }
+            }
+          }
+        }
+        CD_PROBE_ONLY(pr_rows += probe_time() - pr_c1;)
+        continue;
+      }
+      for (int r0 = 0; r0 < TM; r0 += rpp) {
+        const int row = r0 + vr;
+        const int m = m0 + wm * TM + row;
+        if (row < TM && m < p.M && n < p.N) {
+        float v[8];
+        {
+          const f32x4 lo = *(const f32x4*)(E + row * T::EPI_LD + col);
+          const f32x4 hi = *(const f32x4*)(E + row * T::EPI_LD + col + 4);
+          v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+          v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bias_v[e];
+        int on = n;  // output column
+        if (geglu) {
+          float gt[8];
+          const f32x4 lo = *(const f32x4*)(E + row * T::EPI_LD + col + 32);
+          const f32x4 hi = *(const f32x4*)(E + row * T::EPI_LD + col + 36);
+          gt[0] = lo[0]; gt[1] = lo[1]; gt[2] = lo[2]; gt[3] = lo[3];
+          gt[4] = hi[0]; gt[5] = hi[1]; gt[6] = hi[2]; gt[7] = hi[3];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float gg = gt[e] + (p.bias ? p.bias[n + 32 + e] : 0.0f);  // (this loop serves odd shapes only)
+            v[e] = v[e] * gelu_fast(gg);
+          }
+          on = (n / 64) * 32 + (n % 64);
+        } else {
+          if (p.rowvec) {
+            const int rvi = (p.rows_per_vec >= p.M) ? 0 : m / p.rows_per_vec;  // shared timestep: one vector
+            const float* rv = p.rowvec + (int64_t)rvi * p.rowvec_ld + n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += rv[e];
+          }
+          if (p.act == ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+          } else if (p.act == ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              v[e] = gelu_fast(v[e]);
+              // (16-wave tiles live on 128 registers: eight interleaved evaluations spill - two groups of four, the second
+              // one's inputs defined by the empty statement that consumes the first one's results)
+              if constexpr (NW == 16) {
+                if (e == 3) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+              }
+            }
+          } else if (p.act == ACT_QGELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
+          }
+        }
+        if (p.resid && p.resid_f32) {
+          const float* rp = (const float*)p.resid + (int64_t)zb * p.o_bs + (int64_t)m * p.resid_ld + on;
+          if (nvalid == 8 && ((p.resid_ld & 3) == 0)) {
+            const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += rp[e];
+          }
+        } else if (p.resid) {
+          const bf16_t* rp = p.resid + (int64_t)zb * p.o_bs + (int64_t)m * p.resid_ld + on;
+          if (nvalid == 8 && ((p.resid_ld & 7) == 0)) {
+            float rr[8];
+            unpack8(*(const uint4*)rp, rr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rr[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += bf2f(rp[e]);
+          }
+        }
+        CD_PROBE_ONLY(if (!(p.dbg & 1)))
+        if (p.out_f32) {
+          float* op = (float*)outp + (int64_t)m * p.out_ld + on;
+          if (nvalid == 8 && ((p.out_ld & 3) == 0)) {
+            *(f32x4*)op = (f32x4){v[0], v[1], v[2], v[3]};
+            *(f32x4*)(op + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < nvalid) op[e] = v[e];
+          }
+        } else {
+          bf16_t* op = (bf16_t*)outp + (int64_t)m * p.out_ld + on;
+          if (nvalid == 8 && ((p.out_ld & 7) == 0)) {
+            *(uint4*)op = pack8(v);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < nvalid) op[e] = f2bf(v[e]);
+          }
+        }
+        CD_PROBE_ONLY(if (p.dbg & 1) { if (v[0] == 1.2345e-33f) ((float*)outp)[0] = v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7]; })
+        if (p.stats) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+        }
+        }  // valid row
+        if (p.stats && ((r0 + rpp) & 31) == 0) {
+          // end of a 32-row block: fold the lanes that share this column vector (same vc, different vr)
+          for (int o = vpr; o < 64; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ssum[e] += __shfl_xor(ssum[e], o); ssq[e] += __shfl_xor(ssq[e], o); }
+          }
+          const int rb = (m0 + wm * TM + r0 + rpp - 32) >> 5;
+          if (vr == 0 && n < p.N && (rb << 5) < p.M) {
+            float* sp = p.stats + ((int64_t)zb * ((p.M + 31) >> 5) + rb) * 2 * p.N + n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < nvalid) { sp[e] = ssum[e]; sp[p.N + e] = ssq[e]; }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+        }
+      }
+      CD_PROBE_ONLY(pr_rows += probe_time() - pr_c1;)
+    }
   }
   CD_PROBE_ONLY({
     pr_issued = probe_time();
@@ -798,9 +955,9 @@ int launch_cfg(hipStream_t st, const ConvGemmParams& p) {
   const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
   const int split = p.splitk > 1 ? p.splitk : 1;
 #ifdef CD_PROBE
-  constexpr int kLds = T::LDS_BYTES + T::NW * 256;  // + the per-wave stamp log
+  constexpr int kLds = T::LDS_BYTES + T::TAB_BYTES + T::NW * 256;  // + the per-wave stamp log
 #else
-  constexpr int kLds = T::LDS_BYTES;
+  constexpr int kLds = T::LDS_BYTES + T::TAB_BYTES;
 #endif
   // channel-major K order (ConvGemmParams::korder): 3 x 3 .. 8 x 8 filters without upsampling; everything else - 1 x 1, the
   // CLIP patch embeddings, the nearest-x2 convs - runs the tap-major instantiation

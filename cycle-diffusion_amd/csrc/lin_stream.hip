@@ -416,8 +416,7 @@ __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) vv[ps][e] = v[e];
             } else {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = vv[ps][e] * gelu_fast(v[e]);
+              mul_gelu8(vv[ps], v, v);
               if (rows_ok) {
                 const uint4 o = pack8_sat(v);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_o, o_lane,

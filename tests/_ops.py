@@ -75,7 +75,7 @@ def conv2d(eng, x0, w, x1=None, stride=1, pad=1, asym=False, up=False, bias=None
     return y.cpu()
 
 
-def conv2d16(eng, x0, w, stride=1, pad=1, bias=None, resid=None, act=0, tile=0, geglu=False, want_stats=False):
+def conv2d16(eng, x0, w, stride=1, pad=1, bias=None, resid=None, act=0, tile=0, geglu=False, want_stats=False, rowvec=None):
     """cd_op_conv2d_16: the convolution with the engine's 16-bit output (+ the fused GroupNorm statistics)"""
     handle, (N, Cin, KH, KW) = pack_conv(eng, w, geglu)
     B, C0, H, W = x0.shape
@@ -88,8 +88,9 @@ def conv2d16(eng, x0, w, stride=1, pad=1, bias=None, resid=None, act=0, tile=0, 
         b = dev(geglu_pack_vec(bias) if geglu else bias)
     xs0 = dev(x0)
     rs = dev(resid) if resid is not None else None
+    rv = dev(rowvec) if rowvec is not None else None
     check(eng.lib.cd_op_conv2d_16(eng.h, ptr(xs0), C0, None, 0, B, H, W, handle, N, KH, KW, stride, pad, 0, 0, ptr(b),
-                                  None, ptr(rs), act, tile, ptr(y), ptr(st)))
+                                  ptr(rv), ptr(rs), act, tile, ptr(y), ptr(st)))
     torch.cuda.synchronize()
     return (y.cpu(), st.cpu()) if want_stats else y.cpu()
 

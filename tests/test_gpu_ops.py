@@ -157,6 +157,61 @@ def test_conv_splitk_repeatable(engine, report):
     _check(report, "conv2d/splitk_repeat", outs[0], ref, rel=5e-3, mean=2e-3)
 
 
+# ---- the 16-bit epilogue of k_conv_gemm (what every ResBlock / transformer projection runs; test_conv2d above goes through
+# the fp32-output path): stores and residual loads through row-bounded buffer descriptors, bias / time-embedding rows from the
+# LDS tables the prologue copies, GroupNorm statistics per 32-row block - on every tile family, with and without each operand,
+# rows beyond M, an image size that is not a power of two (the tables' row index is then a division), columns beyond N
+FAST_EPI_CASES = [
+    # name, B, C, H, W, N, k, bias, rowvec, resid, stats, tile
+    ("t20_all", 2, 64, 16, 16, 320, 3, True, True, True, True, 20),
+    ("t20_plain", 2, 64, 16, 16, 640, 1, False, False, False, False, 20),
+    ("t20_rowvec_only", 3, 64, 8, 8, 320, 1, False, True, False, True, 20),
+    ("t20_resid_ragged", 3, 64, 10, 10, 320, 3, True, False, True, False, 20),
+    ("t20_rows96_per_image", 5, 64, 8, 12, 320, 1, True, True, True, True, 20),
+    ("t20_N200_masked", 2, 64, 16, 16, 200, 1, True, True, True, True, 20),
+    ("t23_all", 2, 64, 16, 16, 320, 3, True, True, True, True, 23),
+    ("t21_all", 2, 64, 16, 16, 320, 1, True, True, True, True, 21),
+    ("t22_all", 2, 64, 16, 16, 512, 1, True, True, True, True, 22),
+    ("t22_rows96", 3, 64, 8, 12, 256, 3, True, True, False, True, 22),
+    ("t5_all", 2, 64, 16, 16, 128, 3, True, True, True, True, 5),
+    ("t6_all", 2, 64, 16, 16, 256, 1, True, True, True, True, 6),
+    ("t18_16waves", 2, 64, 16, 16, 128, 1, True, True, True, True, 18),
+    ("t19_16waves", 2, 64, 16, 16, 128, 3, True, True, True, True, 19),
+    ("t1_all", 2, 64, 16, 16, 128, 3, True, True, True, True, 1),
+    ("t3_rows96_ragged_tile", 3, 64, 8, 12, 64, 1, True, True, True, True, 3),
+    ("t9_no_tables", 2, 64, 16, 16, 64, 1, True, True, True, True, 9),
+    ("t24_two_per_cu", 2, 64, 16, 16, 256, 1, True, True, True, True, 24),
+    ("t20_split3", 2, 320, 8, 8, 320, 3, True, True, True, True, 20 | (3 << 8)),
+]
+
+
+@pytest.mark.parametrize("case", FAST_EPI_CASES, ids=[c[0] for c in FAST_EPI_CASES])
+def test_conv2d_16bit_epilogue(engine, report, case):
+    name, B, C, H, W, N, k, has_bias, has_rv, has_res, stats, tile = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % (2 ** 31))
+    x = r16(torch.randn(B, C, H, W, generator=g))
+    w = r16(torch.randn(N, C, k, k, generator=g) / math.sqrt(C * k * k))
+    bias = torch.randn(N, generator=g) * 0.5 if has_bias else None
+    rv = torch.randn(B, N, generator=g) if has_rv else None
+    ref = F.conv2d(x, w, bias, padding=k // 2)
+    if rv is not None:
+        ref = ref + rv[:, :, None, None]
+    res = r16(torch.randn(ref.shape, generator=g)) if has_res else None
+    if res is not None:
+        ref = ref + res
+    out = _ops.conv2d16(engine, x, w, pad=k // 2, bias=bias, rowvec=rv, resid=res, tile=tile, want_stats=stats)
+    got, st = out if stats else (out, None)
+    _check(report, "conv2d16/" + name, got, ref, rel=5e-3, mean=2e-3)
+    if stats:  # sums over 32-row blocks of the NHWC row order, of the values before their 16-bit rounding
+        rows = ref.permute(0, 2, 3, 1).reshape(-1, N).double()
+        assert rows.shape[0] % 32 == 0
+        blk = rows.reshape(-1, 32, N)
+        want = torch.stack([blk.sum(1), (blk * blk).sum(1)], 1).float()
+        err = (st - want).abs().max().item() / max(want.abs().max().item(), 1e-6)
+        report.add("conv2d16_stats/" + name, rel=err)
+        assert err < 2e-3, (name, err)
+
+
 def test_conv_geglu(engine, report):
     g = torch.Generator().manual_seed(7)
     M, K, N = 512, 320, 2560  # GEGLU.proj: dim -> 2*inner (attention.py:37-44)
