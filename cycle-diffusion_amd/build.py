@@ -54,6 +54,10 @@ def build(force=False, verbose=False, variant=None):
         objdir = os.path.join(HERE, "build", "geluold")
         lib = os.path.join(LIBDIR, "libcyclediff_geluold.so")
         defines = ["-DCD_GELU_SELECT_FORM"]
+    elif variant in ("ntst", "ntld"):  # round-6 A/B: streaming (nt) output stores / residual loads of the GEMM epilogue (measurement only)
+        objdir = os.path.join(HERE, "build", variant)
+        lib = os.path.join(LIBDIR, "libcyclediff_%s.so" % variant)
+        defines = ["-DCD_EPI_STORE_AUX=2"] if variant == "ntst" else ["-DCD_EPI_RESID_AUX=2"]
     elif variant is not None:
         raise ValueError("unknown build variant %r" % (variant,))
     os.makedirs(LIBDIR, exist_ok=True)
@@ -90,6 +94,5 @@ def build(force=False, verbose=False, variant=None):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, variant="bf16" if "--bf16" in sys.argv else ("probe" if "--probe" in sys.argv else
-                                                                   ("pack8old" if "--pack8old" in sys.argv else
-                                                                    ("geluold" if "--geluold" in sys.argv else None)))))
+    _variant = next((v for v in ("bf16", "probe", "pack8old", "geluold", "ntst", "ntld") if "--" + v in sys.argv), None)
+    print(build(force="--force" in sys.argv, verbose=True, variant=_variant))

@@ -33,6 +33,15 @@ namespace cd {
 
 namespace gemm_detail {
 
+// cache-policy bits of the fast epilogue's output stores / residual loads (2 = nt: streaming). A/B builds only
+// (build.py --ntst / --ntld): measured round 6, see docs/optimisation_log.md
+#ifndef CD_EPI_STORE_AUX
+#define CD_EPI_STORE_AUX 0
+#endif
+#ifndef CD_EPI_RESID_AUX
+#define CD_EPI_RESID_AUX 0
+#endif
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -99,6 +108,15 @@ __device__ __forceinline__ unsigned long long probe_realtime() {
 #else
 #define CD_PROBE_ONLY(...)
 #endif
+
+// A buffer descriptor for the epilogue. The words go through v_readfirstlane: behind the split-K fix-up's data-dependent return
+// the compiler no longer treats them as wave-uniform and would wrap every buffer operation in a waterfall loop.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, int bytes) {
+  const uint64_t u = (uint64_t)base;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
 
 // the straight-line epilogue (16-bit output, no activation, 16-byte aligned rows): see the kernel's epilogue
 __device__ __forceinline__ bool fast_epilogue(const ConvGemmParams& p) {
@@ -373,9 +391,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
   constexpr int TABI = T::HAS_TAB ? (TAB_N + NW - 1) / NW : 0;        // ... per wave
   if constexpr (TABI > 0) {
     const bool fe = fast_epilogue(p);
+    const bool tb = (fe || p.act == ACT_GEGLU) && p.bias != nullptr;  // the GEGLU block epilogue takes its two bias vectors from the table too
     char* tab = smem + T::LDS_BYTES;
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((fe && p.bias) ? (const void*)p.bias : (const void*)p.wgt), 0, (fe && p.bias) ? p.N * 4 : 0, 0x00020000);
+        (void*)(tb ? (const void*)p.bias : (const void*)p.wgt), 0, tb ? p.N * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((fe && p.rowvec) ? (const void*)p.rowvec : (const void*)p.wgt), 0, (fe && p.rowvec) ? kRange : 0, 0x00020000);
     const unsigned rpv = (unsigned)p.rows_per_vec;
@@ -570,14 +589,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4e;
     const int mw = m0 + wm * TM;  // first row of the wave tile
     const bool has_res = p.resid != nullptr;
-    // (the descriptor words go through v_readfirstlane: behind the split-K fix-up's data-dependent return the compiler no longer
-    // treats them as wave-uniform and would wrap every buffer operation in a waterfall loop)
-    auto uniform_rsrc = [](const void* base, int bytes) __attribute__((always_inline)) {
-      const uint64_t u = (uint64_t)base;
-      const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
-      const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
-      return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-    };
     int rows_ok = p.M - mw;
     rows_ok = rows_ok < 0 ? 0 : (rows_ok > TM ? TM : rows_ok);
     const int nblk = (p.M + 31) >> 5;
@@ -601,7 +612,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
       const unsigned vo = nx < p.N ? (unsigned)(((rbx * 32 + lane_ep / vprx) * p.resid_ld + nx) * 2) : kInvalid;
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps)
-        if (ps < npx) dst[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, vo + (unsigned)(ps * rppx * p.resid_ld * 2), 0, 0);
+        if (ps < npx) dst[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, vo + (unsigned)(ps * rppx * p.resid_ld * 2), 0, CD_EPI_RESID_AUX);
     };
     if constexpr (PIPE) resid_issue(0, 0, rq[0]);
 #pragma unroll
@@ -670,7 +681,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
             const uint4 pk = pack8(vp);
             CD_PROBE_ONLY(if (!(p.dbg & 1)))
             __builtin_amdgcn_raw_buffer_store_b128((u32x4e){pk.x, pk.y, pk.z, pk.w}, rs_o,
-                                                   vo_blk + (unsigned)(ps * RPP * p.out_ld * 2), 0, 0);
+                                                   vo_blk + (unsigned)(ps * RPP * p.out_ld * 2), 0, CD_EPI_STORE_AUX);
             if constexpr (!KEEP) {
               const float on = (mb + ps * RPP + vr) < p.M ? 1.0f : 0.0f;
 #pragma unroll
@@ -763,6 +774,55 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
       const int col = vc * 8;                            // column inside the chunk
       const int n = n0 + wn * TN + jc * 32 + col;        // packed column
       const int nvalid = (p.N - n) < 8 ? (p.N - n) : 8;
+      // GEGLU (attention.py:37-44: value * gelu(gate)), the feed-forward input projection of every transformer block: the block
+      // form of the fast epilogue. A 64-column chunk = [32 value | 32 gate] columns; 4 lanes cover a row's 32 outputs, 16 rows
+      // per pass; both bias vectors from the prologue's LDS table, stores through a row-bounded descriptor (no row branches).
+      if (geglu && cw == 64 && !p.out_f32 && !p.resid && !p.stats && !p.rowvec && (p.N & 63) == 0 && (p.out_ld & 7) == 0 &&
+          (((uintptr_t)p.out) & 15) == 0 && (p.o_bs & 7) == 0) {
+        constexpr int LD = T::EPI_LD;
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4e;
+        float bias_v[8], bias_g[8];
+        if constexpr (T::HAS_TAB) {
+          const float* tb = (const float*)(smem + T::LDS_BYTES) + wn * TN + jc * 32 + col;
+          const f32x4 x0 = *(const f32x4*)tb, x1 = *(const f32x4*)(tb + 4), g0 = *(const f32x4*)(tb + 32), g1 = *(const f32x4*)(tb + 36);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { bias_v[e] = x0[e]; bias_v[4 + e] = x1[e]; bias_g[e] = g0[e]; bias_g[4 + e] = g1[e]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { bias_v[e] = p.bias ? p.bias[n + e] : 0.0f; bias_g[e] = p.bias ? p.bias[n + 32 + e] : 0.0f; }
+        }
+        const int mw = m0 + wm * TM;
+        int rows_ok = p.M - mw;
+        rows_ok = rows_ok < 0 ? 0 : (rows_ok > TM ? TM : rows_ok);
+        const __amdgpu_buffer_rsrc_t rs_o = uniform_rsrc(outp + (int64_t)mw * p.out_ld * 2, rows_ok * p.out_ld * 2);
+        const unsigned vo_out = n < p.N ? (unsigned)((vr * p.out_ld + (n / 64) * 32 + (n % 64)) * 2) : kInvalid;
+#pragma unroll
+        for (int rb = 0; rb < TM / 32; ++rb) {
+          f32x4 vl[2], vh[2], gl[2], gh[2];
+#pragma unroll
+          for (int ps = 0; ps < 2; ++ps) {
+            const float* er = E + (rb * 32 + ps * 16 + vr) * LD + col;
+            vl[ps] = *(const f32x4*)er;        vh[ps] = *(const f32x4*)(er + 4);
+            gl[ps] = *(const f32x4*)(er + 32); gh[ps] = *(const f32x4*)(er + 36);
+          }
+#pragma unroll
+          for (int ps = 0; ps < 2; ++ps) {
+            float v[8], va[8], ga[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              va[e] = vl[ps][e] + bias_v[e]; va[4 + e] = vh[ps][e] + bias_v[4 + e];
+              ga[e] = gl[ps][e] + bias_g[e]; ga[4 + e] = gh[ps][e] + bias_g[4 + e];
+            }
+            mul_gelu8(va, ga, v);
+            const uint4 pk = pack8(v);
+            CD_PROBE_ONLY(if (!(p.dbg & 1)))
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4e){pk.x, pk.y, pk.z, pk.w}, rs_o,
+                                                   vo_out + (unsigned)((rb * 32 + ps * 16) * p.out_ld * 2), 0, 0);
+          }
+        }
+        CD_PROBE_ONLY(pr_rows += probe_time() - pr_c1;)
+        continue;
+      }
       float bias_v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) bias_v[e] = (p.bias && e < nvalid) ? p.bias[n + e] : 0.0f;
@@ -772,45 +832,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
       float ssum[8], ssq[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
-      // GEGLU (attention.py:37-44: value * gelu(gate)), the feed-forward input projection of every transformer block: the same
-      // block form. A 64-column chunk = [32 value | 32 gate] columns; 4 lanes cover a row's 32 outputs, 16 rows per pass.
-      if (geglu && cw == 64 && !p.out_f32 && !p.resid && !p.stats && !p.rowvec && (p.N & 63) == 0 && (p.out_ld & 7) == 0) {
-        constexpr int LD = T::EPI_LD;
-        bf16_t* const ocol = (bf16_t*)outp + (n / 64) * 32 + (n % 64);
-        float bias_g[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bias_g[e] = p.bias ? p.bias[n + 32 + e] : 0.0f;
-#pragma unroll
-        for (int rb = 0; rb < TM / 32; ++rb) {
-          const int mb = m0 + wm * TM + rb * 32;
-          if (mb < p.M) {
-            f32x4 vl[2], vh[2], gl[2], gh[2];
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-              const float* er = E + (rb * 32 + ps * 16 + vr) * LD + col;
-              vl[ps] = *(const f32x4*)er;        vh[ps] = *(const f32x4*)(er + 4);
-              gl[ps] = *(const f32x4*)(er + 32); gh[ps] = *(const f32x4*)(er + 36);
-            }
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-              float v[8], va[8], ga[8];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                va[e] = vl[ps][e] + bias_v[e]; va[4 + e] = vh[ps][e] + bias_v[4 + e];
-                ga[e] = gl[ps][e] + bias_g[e]; ga[4 + e] = gh[ps][e] + bias_g[4 + e];
-              }
-              mul_gelu8(va, ga, v);
-              const int m = mb + ps * 16 + vr;
-              if (m < p.M && n < p.N) {
-                CD_PROBE_ONLY(if (!(p.dbg & 1)))
-                *(uint4*)(ocol + (int64_t)m * p.out_ld) = pack8(v);
-              }
-            }
-          }
-        }
-        CD_PROBE_ONLY(pr_rows += probe_time() - pr_c1;)
-        continue;
-      }
       for (int r0 = 0; r0 < TM; r0 += rpp) {
         const int row = r0 + vr;
         const int m = m0 + wm * TM + row;
