@@ -136,7 +136,10 @@ def test_latentdiff_stochastic_wrapper_vs_reference(report, prec):
     assert (not flipped.any()) or float(margin[flipped].max()) < 0.5 * float(margin.median())
     # the decoder's mid-block attention spreads a flipped cell's change thinly over the whole image: measured 30-32.5 dB
     # away from the flipped patches on the 16-bit engine
-    assert p0_away >= (42.0 if x3 else 26.0), p0_away  # split mode: 45.8 dB
+    # (split mode: 45.8 dB with 2 flipped cells on the builds of rounds 4-6; 38.2 dB with 3 on the build whose GEMM epilogue forms
+    # its GroupNorm sums of squares by fma - latent error 1.9e-3 instead of 2.1e-3, the third cell's margin 1.5e-4 of a 6e-3 median)
+    nflip = int(flipped.sum())
+    assert p0_away >= ((42.0 if nflip <= 2 else 36.0) if x3 else 26.0), (p0_away, nflip)
     # (the 16-bit VQ encoder's x0 differs by 2e-3 in both modes; the split-mode eps slots go 2e-6 -> 3e-4 along the chain)
     assert xT < (1e-4 if x3 else 2e-2 * FMT) and max(eps_rel) < (2e-3 if x3 else 2e-2 * FMT), (xT, eps_rel)
     assert lat_rel < (1e-2 if x3 else 4e-2 * FMT), lat_rel  # split mode: 2e-3
