@@ -140,6 +140,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  // (launch_bounds below) two workgroups per CU: de-phase them once per launch, see ConvGemmParams::dephase_ticks
+  if constexpr (WM * WN == 4 && BK == 32 && NSTAGE == 3 && BM * BN >= 128 * 256) {
+    if (p.dephase_ticks > 0 && (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) < 2 * p.num_cus) {
+      unsigned hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      if (tid == 0) *(volatile int*)smem = (int)(hwid & 1u);  // wave slot of wave 0: the second workgroup of a SIMD sits in slot 1
+      __syncthreads();
+      const int odd = *(volatile int*)smem;
+      __syncthreads();
+      if (odd) {
+        unsigned long long t0, t1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+        do {
+          __builtin_amdgcn_s_sleep(32);
+          asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+        } while ((long long)(t1 - t0) < (long long)p.dephase_ticks);
+      }
+    }
+  }
   CD_PROBE_ONLY(
   const unsigned long long pr_rt0 = probe_realtime();
   unsigned long long pr_t0 = probe_time(), pr_prol = 0, pr_first = 0, pr_wait = 0, pr_comp = 0, pr_maxw = 0, pr_loop = 0,
@@ -1357,6 +1376,9 @@ void launch_conv_gemm(hipStream_t st, const ConvGemmParams& p) {
   if (tg_env > 0 && p.N >= tg_min_n && p.nbatch == 1) pk.tile_group = tg_env;
 #ifdef CD_PROBE
   if (const char* e = getenv("CYCLEDIFF_PROBE_DBG")) pk.dbg = atoi(e);
+  static const int dephase_env = [] { const char* e = getenv("CYCLEDIFF_DEPHASE_TICKS"); return e ? atoi(e) : 0; }();
+  pk.dephase_ticks = dephase_env;
+  pk.num_cus = device_cu_count();
   if (pk.dbg & 2) pk.stats = nullptr;
 #endif
   static const CfgInfo kLinStreamCfg = {kLinStreamTile, 256, 64, 64, "lin_stream 256 x N, K = 320"};

@@ -107,6 +107,11 @@ struct ConvGemmParams {
   // G > 0 = groups of G row tiles walked m-fastest (the 32 CUs of an XCD then run G row tiles x 32 / G column tiles at a time:
   // G A panels + 32 / G W panels in its L2 instead of 1 + 32) - for the wide-N layers whose operands both exceed the L2
   int tile_group = 0;
+  // two-per-CU tile configurations (24, 25) only: the workgroups of the launch's first wave front that sit in an odd wave slot
+  // wait this many shader cycles before they start, so that the two co-resident workgroups of a CU run half a tile apart (one's
+  // prologue / epilogue under the other's K loop). 0 = off. Experiment of round 6 (CYCLEDIFF_DEPHASE_TICKS), docs/optimisation_log.md
+  int dephase_ticks = 0;
+  int num_cus = 256;
   int dbg = 0;  // probe build: 1 = the epilogue skips its global stores, 2 = skips the statistics, 4 = every tile gathers
                 // its A rows from the first 1024 + BM rows (an L2-resident operand: what would the K loop do without misses?)
 };
