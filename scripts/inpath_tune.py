@@ -53,7 +53,7 @@ def label_key(k):  # what the GEMM log prints for a table key
 def run_forward(table_path, B):
     env = dict(os.environ, CYCLEDIFF_TUNE_DEFAULT=table_path, CYCLEDIFF_GEMM_LOG="1", PYTHONPATH=ROOT)
     env.pop("CYCLEDIFF_TUNE_CACHE", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_unet.py"), str(B), "1", "gemmlog"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_unet.py"), str(B), os.environ.get("INPATH_ITERS", "1"), "gemmlog"],
                        env=env, capture_output=True, text=True, timeout=600)
     out = {}
     for ln in r.stderr.splitlines():
