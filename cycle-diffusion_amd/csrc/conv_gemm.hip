@@ -421,8 +421,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && BK == 32 && NSTAGE =
     const int rpv_sh = 31 - __builtin_clz(rpv | 1u);
 #pragma unroll
     for (int i = 0; i < TABI; ++i) {
-      int j = i * NW + wave;  // (uniform) copy number: bias copies first
-      if (j >= TAB_N) j -= TAB_N;
+      const int j = (i * NW + wave) % TAB_N;  // (uniform) copy number, bias copies first; past the last copy: an earlier one again
       if (j < T::TAB_BIAS_I) {
         const int c4 = j * 64 + lane;  // 16-byte chunk of the bias row (beyond BN: the next tile's columns or zeros, unused)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lptr_t)(tab + j * 1024), 16, (unsigned)((n0 + c4 * 4) * 4), 0, 0, 0);
