@@ -217,6 +217,18 @@ __device__ inline void mul_gelu8(const float* val, const float* gate, float* out
   }
 }
 
+// out[e] = val[e] * gelu(gate[e]), e = 0 .. 3 (the same operations per element as mul_gelu8)
+__device__ inline void mul_gelu4(const float* val, const float* gate, float* out) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const f32x2 g = {gate[2 * i], gate[2 * i + 1]}, v = {val[2 * i], val[2 * i + 1]};
+    const f32x2 r = v * gelu_fast2(g);
+    out[2 * i] = r[0];
+    out[2 * i + 1] = r[1];
+  }
+}
+
 // ---- error handling: no exception crosses the C ABI -----------------------------------------
 struct Error : public std::runtime_error {
   explicit Error(const std::string& m) : std::runtime_error(m) {}

@@ -142,6 +142,7 @@ struct LinStreamParams {
   float* stats = nullptr;
   int M = 0, N = 0;
   float ln_eps = 1e-5f;  // LayerNorm-folded variants
+  int geglu_direct = 0;  // GEGLU epilogue straight from the accumulators (no LDS transpose), lin_stream.hip
 };
 constexpr int kLinStreamTile = 30;
 bool lin_stream_supports(const ConvGemmParams& p);

@@ -45,6 +45,7 @@ constexpr int OFF_A = WSLOTS * WPIECE, OFF_ST = OFF_A + ASLOTS * APIECE, OFF_BIA
 constexpr int LDS_BYTES = OFF_BIAS + BIAS_MAX * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 constexpr unsigned kNoLoad = 0x80000000u;
+constexpr int kGegluDirectDefault = 1;  // LinStreamParams::geglu_direct unless CYCLEDIFF_GEGLU_DIRECT says otherwise
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (rounded DOWN to a multiple of 4: waiting for a few more
 // operations than necessary is always correct)
@@ -391,6 +392,30 @@ __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
       asm volatile("" : "+v"(l2));  // as above: nothing lane-derived stays live across the MFMA loop
       const int prow = l2 >> 2, pcol = (l2 & 3) * 8, mi2 = l2 & 31, half2 = l2 >> 5;
       const unsigned o_lane = (unsigned)(((wave * 32 + prow) * p.ldo + pcol) * 2);
+      if (GEGLU && p.geglu_direct) {
+        // GEGLU straight from the accumulators: value (acc[0]) and gate (acc[1]) of an output element sit in the same
+        // register of the same lane, so the tile needs no transpose - the LDS round trip of the staged form (4 writes,
+        // a wait, 4 reads per column block, each behind the other) is this epilogue's critical path, not its VALU count
+        // (round 6: running the SIMD's two waves' epilogues one after the other instead of against each other LOST 5 %).
+        // A lane stores 4 consecutive columns of its row per register quad (8 bytes; lanes l and l + 32 are neighbours).
+        // Same operations per element as the staged form (bias add, gelu_fast2 on column pairs, product, one rounding).
+        const unsigned od_lane = (unsigned)(((wave * 32 + mi2) * p.ldo + 4 * half2) * 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float* bp = bias_s + t * 64 + 8 * q + 4 * half2;
+          const f32x4 bv = *(const f32x4*)bp, bg = *(const f32x4*)(bp + 32);
+          float val[4], gate[4], o4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { val[j] = acc[0][4 * q + j] + bv[j]; gate[j] = acc[1][4 * q + j] + bg[j]; }
+          mul_gelu4(val, gate, o4);
+          if (rows_ok) {
+            typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+            const u32x2 o = {pack2(o4[0], o4[1]), pack2(o4[2], o4[3])};
+            __builtin_amdgcn_raw_buffer_store_b64(o, rs_o, od_lane, (row0 * p.ldo + t * 32 + 8 * q) * 2, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // one register quad at a time
+        }
+      } else {
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
         __builtin_amdgcn_wave_barrier();
@@ -464,6 +489,7 @@ __global__ __launch_bounds__(512, 2) void k_lin_stream(LinStreamParams p) {
           }
         }
       }
+      }  // staged epilogue
       // Stores are NOT counted in `seq`: gfx9-family hardware may retire stores out of order with respect to loads
       // (only loads return in order among themselves), so a count that allowed "the younger stores" to be outstanding
       // could be satisfied by early stores while the awaited load is still in flight - seen on hardware as stale A
@@ -561,6 +587,9 @@ void launch_lin_stream(hipStream_t st, const ConvGemmParams& c) {
   }
   const int nstrips = (p.M + 255) / 256;
   const int grid = nstrips < ncu ? nstrips : ncu;
+  // CYCLEDIFF_GEGLU_DIRECT=0 / 1 (A/B runs): the staged / the straight-from-the-accumulators GEGLU epilogue
+  static const int geglu_direct = [] { const char* e = getenv("CYCLEDIFF_GEGLU_DIRECT"); return e && e[0] ? atoi(e) : kGegluDirectDefault; }();
+  p.geglu_direct = geglu_direct;
   if (c.ln_fold) {  // LayerNorm folded in: the feed-forward GEGLU projection and the plain projections behind norm1-3
     p.ln_eps = c.ln_eps;
     CD_CHECK(!c.resid && !c.stats, "lin_stream: a LayerNorm-folded layer has neither residual nor statistics");
